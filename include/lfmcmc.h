@@ -1,0 +1,136 @@
+/*
+ * lfmcmc.h - C ABI of liblfmcmc.so: the per-step log-posterior of LumFuncMCMC on MI355X (gfx950).
+ *
+ * The reference has no FFI: its hot path is a bound Python method handed to emcee,
+ *     emcee.EnsembleSampler(nwalkers, ndim, self.lnprob)          lumfuncmcmc.py:487-489
+ *     emcee.EnsembleSampler(nwalkers, ndim, self.lnprob)          lumfuncmcmc_z.py:444
+ * with signature  f(theta: float64[ndim]) -> float  (-inf outside the prior or on underflow,
+ * never NaN).  This header is the boundary a maintainer would bind instead (ctypes stub in
+ * INTEGRATION.md): plain pointers and sizes, no torch / numpy types.
+ *
+ * Each entry point names the reference interface it replaces (file:line in the reference).
+ *
+ * Threading: one in-flight call per context; lf_create / lf_destroy are not thread-safe.
+ * Ownership: the caller owns every host buffer it passes (they are copied during lf_create);
+ * the library owns all device memory.  No entry point throws; errors are negative return codes
+ * plus a message from lf_last_error().
+ */
+#ifndef LFMCMC_H
+#define LFMCMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_ABI_VERSION 1
+#define LF_MAX_FIELDS 8
+
+/* model variants = the three log-posterior callables of the reference */
+enum {
+    LF_FREE = 0,    /* LumFuncMCMC.lnprob          lumfuncmcmc.py:395-409  (completeness free)  */
+    LF_FIXCOMP = 1, /* LumFuncMCMC.lnprob_fix_comp lumfuncmcmc.py:411-424  (completeness fixed) */
+    LF_ZEVOL = 2    /* LumFuncMCMCz.lnprob         lumfuncmcmc_z.py:378-392 (z-evolving L*, phi*) */
+};
+
+/* return codes */
+enum {
+    LF_OK = 0,
+    LF_ERR_ARG = -1,    /* bad descriptor / NULL pointer / B <= 0                       */
+    LF_ERR_HIP = -2,    /* a HIP runtime call failed (message has the hipError string)   */
+    LF_ERR_NOMEM = -3,  /* host or device allocation failed                              */
+    LF_ERR_NODEV = -4   /* no gfx950 device visible                                      */
+};
+
+/* indices into lf_desc.lims: the *_lims constructor arguments, lumfuncmcmc.py:73-79 */
+enum { LF_LIM_LSTAR = 0, LF_LIM_PHISTAR = 1, LF_LIM_SCH_AL = 2, LF_LIM_FLIM = 3, LF_LIM_ALPHA = 4 };
+
+/*
+ * Everything lnlike reads, i.e. the outputs of the reference's one-off setup
+ * (setDLdVdz / setOmegaLz / setlnsimple / defineFlimOmArr, lumfuncmcmc.py:180-235, :283-288;
+ * lumfuncmcmc_z.py:226-305).  Arrays are float64, C-contiguous.
+ */
+typedef struct lf_desc {
+    int32_t variant;       /* LF_FREE | LF_FIXCOMP | LF_ZEVOL                                   */
+    int32_t fix_sch_al;    /* 1: Schechter alpha is not in theta (lumfuncmcmc.py:330,333)       */
+    int32_t nf;            /* number of fields, 1..LF_MAX_FIELDS (len(Flim), :147)              */
+    int32_t S;             /* size_ln: side of the integration grid (101 free, 201 else; :219)  */
+    int64_t N;             /* number of sources                                                 */
+    const int64_t *field_ind; /* [nf+1] field f = sources field_ind[f] .. field_ind[f+1]-1 (:148) */
+    const double *lum;     /* [N] log10 L (erg/s)                                    self.lum   */
+    const double *logf;    /* [N] FREE: lum - log10(4 pi (3.086e24 DLf(z))^2)   (the flux of :70) */
+    const double *z;       /* [N] ZEVOL: source redshifts                              self.z   */
+    const double *om_arr;  /* [N] FIXCOMP, ZEVOL: Omega(lum_i, z_i) at fixed completeness (:235)  */
+    const double *omega0;  /* [nf] effective areas in sq arcsec, as configured (float).  The
+                              library applies the reference's int truncation for the per-source
+                              term (:285) and uses the float value in the integral (:375).       */
+    const double *logL;    /* [S*S] row-major [j][k]: j = luminosity index, k = redshift index;
+                              the ONE grid every field integrates on (self.logL[-1], :225-232)    */
+    const double *zarr;    /* [S]                                                    self.zarr  */
+    const double *volume_part; /* [S] FREE: dVc/dz/dOmega at zarr                   (:223)      */
+    const double *dl_zarr; /* [S] FREE: DLf(zarr) in Mpc                             (:222)      */
+    const double *integ_part;  /* [nf*S*S] FIXCOMP, ZEVOL: volume_part * Omegaf[f].ev (:233-234) */
+    const double *flim0;   /* [nf] FIXCOMP: the fixed Flim (prior still tests them, :346-351)   */
+    double alpha0;         /* FIXCOMP: the fixed completeness slope                             */
+    double sch_al0;        /* value of alpha when fix_sch_al                                    */
+    double fcmin;          /* modified-Fleming knee, VmaxLumFunc.py:95 (0 < fcmin < 1)          */
+    double lims[5][2];     /* prior boxes, rows LF_LIM_*                                        */
+    double pivots[3];      /* ZEVOL: z1, z2, z3                      lumfuncmcmc_z.py:125       */
+    int32_t device;        /* HIP device ordinal                                                */
+    int32_t max_batch;     /* rows the workspace is sized for up front (grown on demand); 0 = 1024 */
+} lf_desc;
+
+typedef struct lf_ctx lf_ctx;
+
+/* ABI version of the loaded library (== LF_ABI_VERSION of the header it was built from). */
+int lf_abi_version(void);
+
+/* Replaces the read side of LumFuncMCMC.__init__ / LumFuncMCMCz.__init__ (lumfuncmcmc.py:162-177):
+ * copies the catalogue and grids to HBM, derives the parameter-independent per-source and
+ * per-node tables.  Returns NULL on failure; lf_last_error(NULL) then holds the reason. */
+lf_ctx *lf_create(const lf_desc *desc);
+
+/* Releases device and host memory of the context. */
+void lf_destroy(lf_ctx *ctx);
+
+/* Number of free parameters of the variant (pos.shape[1] at lumfuncmcmc.py:485). */
+int lf_ndim(const lf_ctx *ctx);
+
+/* Replaces B serial calls of lnprob / lnprob_fix_comp (lumfuncmcmc.py:395, :411;
+ * lumfuncmcmc_z.py:378).  theta: host, [B][ndim] row-major.  out: host, [B].
+ * out[i] = -INFINITY where the prior fails or the likelihood underflows; never NaN.
+ * Synchronous.  Returns LF_OK or a negative code. */
+int lf_lnprob_batch(lf_ctx *ctx, const double *theta, int B, double *out);
+
+/* Same, with theta and out in device memory of ctx's device and the launches enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the default stream).  Asynchronous: `out` is complete when
+ * the stream reaches this point.  This is the form the multi-GPU path uses (the per-rank slice of
+ * lnprob feeds the RCCL all-gather without a host round trip). */
+int lf_lnprob_batch_device(lf_ctx *ctx, const double *d_theta, int B, double *d_out, void *hip_stream);
+
+/* Diagnostics for parity tests: the two pieces of lnlike separately (host buffers).
+ * outA[i] = per-source log-term sum (lumfuncmcmc.py:370 / :388 / lumfuncmcmc_z.py:371),
+ * outB[i] = expected-count integral (:373-377 / :389-392 / _z:373-375).  Rows failing the prior
+ * get NaN in both.  Synchronous. */
+int lf_lnprob_pieces(lf_ctx *ctx, const double *theta, int B, double *outA, double *outB);
+
+/* Kernel timing for bench.py: when enabled, every launch is bracketed by hipEvents on the
+ * stream it runs on.  lf_kernel_times reads and clears the accumulated totals:
+ * ms[0..3] = {prepare, per-source sum (piece A), grid integral (piece B), finalize},
+ * launches[0..3] the launch counts.  Synchronises the recorded events. */
+int lf_set_profiling(lf_ctx *ctx, int enabled);
+int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
+
+/* Tuning knobs (performance only, never results beyond summation order):
+ * key "src_chunk" (sources per workgroup, multiple of 256, 0 = auto). */
+int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
+
+/* Last error message of this context (or of lf_create when ctx == NULL).  Never NULL. */
+const char *lf_last_error(const lf_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFMCMC_H */

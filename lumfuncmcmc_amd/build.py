@@ -1,0 +1,43 @@
+"""Builds liblfmcmc.so (HIP, gfx950 only) in-tree with hipcc.  No JIT cache, no torch extension:
+the shared object sits next to the sources so it travels with the repo snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liblfmcmc.so")
+SOURCES = [os.path.join(CSRC, "lfmcmc.hip")]
+HEADERS = [os.path.join(CSRC, "lf_kernels.h"), os.path.join(CSRC, "lf_math.h"),
+           os.path.join(os.path.dirname(HERE), "include", "lfmcmc.h")]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build_library(force=False, verbose=True, extra_flags=()):
+    """Compile the C-ABI library for gfx950.  Raises on failure."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"] + list(extra_flags) + ["-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,260 @@
+"""ctypes binding of liblfmcmc.so (include/lfmcmc.h).
+
+There is no CPU fallback: if the shared object is missing or does not load, importing
+callers get a RuntimeError that says so.  Build it with `python -m lumfuncmcmc_amd.build`
+(or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblfmcmc.so")
+
+LF_ABI_VERSION = 1
+LF_MAX_FIELDS = 8
+LF_FREE, LF_FIXCOMP, LF_ZEVOL = 0, 1, 2
+VARIANTS = {"free": LF_FREE, "fixcomp": LF_FIXCOMP, "zevol": LF_ZEVOL}
+LF_OK = 0
+LIM_ORDER = ("Lstar", "phistar", "sch_al", "Flim", "alpha")
+
+MPC_CM = 3.086e24                                  # lumfuncmcmc.py:70
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+class LfDesc(ctypes.Structure):
+    _fields_ = [
+        ("variant", ctypes.c_int32), ("fix_sch_al", ctypes.c_int32),
+        ("nf", ctypes.c_int32), ("S", ctypes.c_int32), ("N", ctypes.c_int64),
+        ("field_ind", _c_int64_p), ("lum", _c_double_p), ("logf", _c_double_p),
+        ("z", _c_double_p), ("om_arr", _c_double_p), ("omega0", _c_double_p),
+        ("logL", _c_double_p), ("zarr", _c_double_p), ("volume_part", _c_double_p),
+        ("dl_zarr", _c_double_p), ("integ_part", _c_double_p), ("flim0", _c_double_p),
+        ("alpha0", ctypes.c_double), ("sch_al0", ctypes.c_double), ("fcmin", ctypes.c_double),
+        ("lims", (ctypes.c_double * 2) * 5), ("pivots", ctypes.c_double * 3),
+        ("device", ctypes.c_int32), ("max_batch", ctypes.c_int32),
+    ]
+
+
+EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_batch",
+           "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
+           "lf_set_option", "lf_last_error")
+
+_lib = None
+
+
+def load():
+    """dlopen liblfmcmc.so and declare the prototypes.  Raises RuntimeError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "liblfmcmc.so not found at %s: the HIP library has not been built "
+            "(run `python -m lumfuncmcmc_amd.build`). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError("liblfmcmc.so failed to load (%s). There is no CPU fallback." % e)
+    lib.lf_abi_version.restype = ctypes.c_int
+    lib.lf_abi_version.argtypes = []
+    lib.lf_create.restype = ctypes.c_void_p
+    lib.lf_create.argtypes = [ctypes.POINTER(LfDesc)]
+    lib.lf_destroy.restype = None
+    lib.lf_destroy.argtypes = [ctypes.c_void_p]
+    lib.lf_ndim.restype = ctypes.c_int
+    lib.lf_ndim.argtypes = [ctypes.c_void_p]
+    lib.lf_lnprob_batch.restype = ctypes.c_int
+    lib.lf_lnprob_batch.argtypes = [ctypes.c_void_p, _c_double_p, ctypes.c_int, _c_double_p]
+    lib.lf_lnprob_batch_device.restype = ctypes.c_int
+    lib.lf_lnprob_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+    lib.lf_lnprob_pieces.restype = ctypes.c_int
+    lib.lf_lnprob_pieces.argtypes = [ctypes.c_void_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]
+    lib.lf_set_profiling.restype = ctypes.c_int
+    lib.lf_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.lf_kernel_times.restype = ctypes.c_int
+    lib.lf_kernel_times.argtypes = [ctypes.c_void_p, _c_double_p, _c_int64_p]
+    lib.lf_set_option.restype = ctypes.c_int
+    lib.lf_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]
+    lib.lf_last_error.restype = ctypes.c_char_p
+    lib.lf_last_error.argtypes = [ctypes.c_void_p]
+    v = lib.lf_abi_version()
+    if v != LF_ABI_VERSION:
+        raise RuntimeError("liblfmcmc.so ABI %d != binding ABI %d: rebuild the library" % (v, LF_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+def log_flux(lum, dl_mpc):
+    """logf_i = lum_i - log10(4 pi (3.086e24 DLf(z_i))^2): log10 of the flux of lumfuncmcmc.py:70."""
+    return np.asarray(lum, dtype=np.float64) - np.log10(4.0 * np.pi * (MPC_CM * np.asarray(dl_mpc, dtype=np.float64)) ** 2)
+
+
+class LFError(RuntimeError):
+    pass
+
+
+class LFContext(object):
+    """One catalogue + grids resident on one MI355X.  `inp` uses the reference's own names
+    (the attributes LumFuncMCMC / LumFuncMCMCz build in __init__):
+
+        variant, fix_sch_al, sch_al0, field_ind, lum, DLz | logf, z, Om_arr, Omega_0, Flim0, alpha0,
+        logL (S,S), zarr, volume_part, DL_zarr, integ_part (nf,S,S) | integ_sum (S,S), fcmin,
+        lims {Lstar, phistar, sch_al, Flim, alpha}, pivots
+    """
+
+    def __init__(self, inp, device=0, max_batch=0):
+        lib = load()
+        self._lib = lib
+        self._h = None
+        variant = inp["variant"]
+        if variant not in VARIANTS:
+            raise ValueError("variant must be one of %s" % (sorted(VARIANTS),))
+        self.variant = variant
+        fi = np.ascontiguousarray(inp["field_ind"], dtype=np.int64)
+        nf = len(fi) - 1
+        lum = _f64(inp["lum"])
+        N = lum.shape[0]
+        logL = _f64(inp["logL"])
+        S = logL.shape[0]
+        if logL.shape != (S, S):
+            raise ValueError("logL must be (S, S)")
+        keep = {"fi": fi, "lum": lum, "logL": logL, "zarr": _f64(inp["zarr"]),
+                "omega0": _f64(inp["Omega_0"])}
+        d = LfDesc()
+        d.variant = VARIANTS[variant]
+        d.fix_sch_al = 1 if inp.get("fix_sch_al", False) else 0
+        d.nf, d.S, d.N = nf, S, N
+        if variant == "free":
+            if inp.get("logf") is not None:
+                keep["logf"] = _f64(inp["logf"])
+            else:
+                keep["logf"] = _f64(log_flux(lum, inp["DLz"]))
+            keep["volume_part"] = _f64(inp["volume_part"])
+            keep["dl_zarr"] = _f64(inp["DL_zarr"])
+        else:
+            keep["om_arr"] = _f64(inp["Om_arr"])
+            ip = inp.get("integ_part")
+            if ip is None:        # a field-summed table: field 0 carries the sum, the rest are zero
+                ip = np.zeros((nf, S, S))
+                ip[0] = inp["integ_sum"]
+            keep["integ_part"] = _f64(ip)
+            if keep["integ_part"].shape != (nf, S, S):
+                raise ValueError("integ_part must be (nf, S, S)")
+            if variant == "zevol":
+                keep["z"] = _f64(inp["z"])
+            else:
+                keep["flim0"] = _f64(inp["Flim0"])
+                d.alpha0 = float(inp["alpha0"])
+        for k in ("logf", "z", "om_arr", "volume_part", "dl_zarr", "integ_part", "flim0"):
+            setattr(d, k, _ptr(keep.get(k)))
+        d.field_ind = fi.ctypes.data_as(_c_int64_p)
+        d.lum = _ptr(lum)
+        d.omega0 = _ptr(keep["omega0"])
+        d.logL = _ptr(logL)
+        d.zarr = _ptr(keep["zarr"])
+        d.sch_al0 = float(inp.get("sch_al0", 0.0))
+        d.fcmin = float(inp.get("fcmin", 0.1))
+        lims = inp["lims"]
+        for i, name in enumerate(LIM_ORDER):
+            d.lims[i][0], d.lims[i][1] = float(lims[name][0]), float(lims[name][1])
+        piv = inp.get("pivots", (1.20, 1.53, 1.86))
+        for i in range(3):
+            d.pivots[i] = float(piv[i])
+        d.device = int(device)
+        d.max_batch = int(max_batch)
+        h = lib.lf_create(ctypes.byref(d))
+        if not h:
+            raise LFError(lib.lf_last_error(None).decode())
+        self._h = ctypes.c_void_p(h)
+        self.ndim = lib.lf_ndim(self._h)
+        self.N, self.nf, self.S = N, nf, S
+        self.device = int(device)
+
+    # ------------------------------------------------------------------ calls
+    def _check(self, rc):
+        if rc != LF_OK:
+            raise LFError("liblfmcmc error %d: %s" % (rc, self._lib.lf_last_error(self._h).decode()))
+
+    def _theta(self, theta):
+        th = np.ascontiguousarray(np.atleast_2d(np.asarray(theta, dtype=np.float64)))
+        if th.ndim != 2 or th.shape[1] != self.ndim:
+            raise ValueError("theta must be (B, %d), got %s" % (self.ndim, th.shape))
+        return th
+
+    def lnprob_batch(self, theta):
+        """theta (B, ndim) or (ndim,) host array -> lnprob (B,) float64."""
+        th = self._theta(theta)
+        out = np.empty(th.shape[0], dtype=np.float64)
+        if th.shape[0] == 0:
+            return out
+        self._check(self._lib.lf_lnprob_batch(self._h, _ptr(th), th.shape[0], _ptr(out)))
+        return out
+
+    def lnprob_pieces(self, theta):
+        th = self._theta(theta)
+        a = np.empty(th.shape[0], dtype=np.float64)
+        b = np.empty(th.shape[0], dtype=np.float64)
+        if th.shape[0] == 0:
+            return a, b
+        self._check(self._lib.lf_lnprob_pieces(self._h, _ptr(th), th.shape[0], _ptr(a), _ptr(b)))
+        return a, b
+
+    def lnprob_batch_device(self, theta_ptr, B, out_ptr, stream=0):
+        """Raw device pointers (ints) and a hipStream_t handle (int, 0 = default stream)."""
+        self._check(self._lib.lf_lnprob_batch_device(self._h, ctypes.c_void_p(theta_ptr), int(B),
+                                                     ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream)))
+
+    def lnprob_torch(self, theta, out=None):
+        """theta: CUDA(=HIP) float64 tensor (B, ndim) on this context's device; enqueues on
+        torch's current stream and returns a (B,) tensor.  torch is plumbing here: device memory
+        and streams only."""
+        import torch
+        if theta.dtype != torch.float64 or not theta.is_cuda or theta.dim() != 2 or theta.shape[1] != self.ndim:
+            raise ValueError("theta must be a float64 device tensor of shape (B, %d)" % self.ndim)
+        if theta.device.index != self.device:
+            raise ValueError("theta is on device %s, context is on %d" % (theta.device, self.device))
+        theta = theta.contiguous()
+        B = theta.shape[0]
+        if out is None:
+            out = torch.empty(B, dtype=torch.float64, device=theta.device)
+        if B:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+            self.lnprob_batch_device(theta.data_ptr(), B, out.data_ptr(), stream)
+        return out
+
+    def set_profiling(self, on):
+        self._check(self._lib.lf_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_times(self):
+        ms = (ctypes.c_double * 4)()
+        n = (ctypes.c_int64 * 4)()
+        self._check(self._lib.lf_kernel_times(self._h, ms, n))
+        names = ("prepare", "srcsum", "gridsum", "finalize")
+        return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
+
+    def set_option(self, key, value):
+        self._check(self._lib.lf_set_option(self._h, key.encode(), int(value)))
+
+    def close(self):
+        if self._h is not None:
+            self._lib.lf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,537 @@
+// lfmcmc.hip - C ABI (include/lfmcmc.h) over the gfx950 kernels in lf_kernels.h.
+//
+// Host side of the boundary: copies the catalogue and grids to HBM once, derives the
+// parameter-independent tables (P_i, U_i, trapezoid weights, field-summed integrand), and per
+// call enqueues prepare -> per-source sum -> grid integral -> finalize on one HIP stream.
+#include "../../include/lfmcmc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "lf_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct ChunkTable {
+    int n = 0;
+    int* d_start = nullptr;
+    int* d_len = nullptr;
+    int* d_field = nullptr;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;
+};
+
+}  // namespace
+
+struct lf_ctx {
+    lf::KConst kc{};
+    int device = 0;
+    int64_t N = 0;
+    int nnodes = 0;
+    std::vector<int64_t> field_ind;
+    // device tables
+    double *d_lum = nullptr, *d_a1 = nullptr, *d_P = nullptr, *d_U = nullptr;
+    double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr;
+    std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
+    int64_t opt_src_chunk = 0;
+    // workspace
+    int cap_B = 0;                      // padded walker capacity
+    size_t cap_partA = 0, cap_partB = 0;
+    double *d_theta = nullptr, *d_out = nullptr, *d_outA = nullptr, *d_outB = nullptr;
+    double *d_wrec = nullptr, *d_partA = nullptr, *d_partB = nullptr;
+    int* d_prior = nullptr;
+    double *h_theta = nullptr, *h_out = nullptr;   // pinned staging
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the previous enqueue (workspace is shared)
+    bool any_enqueued = false;
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> events;
+    double acc_ms[4] = {0, 0, 0, 0};
+    int64_t acc_n[4] = {0, 0, 0, 0};
+    std::string err;
+};
+
+namespace {
+
+#define LF_HIP(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            return LF_ERR_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+template <typename T>
+int upload(lf_ctx* c, T** dst, const T* src, size_t n) {
+    LF_HIP(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) LF_HIP(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return LF_OK;
+}
+
+int get_chunks(lf_ctx* c, int ch, ChunkTable** out) {
+    auto it = c->chunks.find(ch);
+    if (it != c->chunks.end()) {
+        *out = &it->second;
+        return LF_OK;
+    }
+    std::vector<int> st, ln, fl;
+    for (int f = 0; f < c->kc.nf; ++f) {
+        for (int64_t s = c->field_ind[f]; s < c->field_ind[f + 1]; s += ch) {
+            st.push_back((int)s);
+            ln.push_back((int)std::min<int64_t>(ch, c->field_ind[f + 1] - s));
+            fl.push_back(f);
+        }
+    }
+    ChunkTable t;
+    t.n = (int)st.size();
+    int rc;
+    if ((rc = upload(c, &t.d_start, st.data(), st.size())) != LF_OK) return rc;
+    if ((rc = upload(c, &t.d_len, ln.data(), ln.size())) != LF_OK) return rc;
+    if ((rc = upload(c, &t.d_field, fl.data(), fl.size())) != LF_OK) return rc;
+    c->chunks[ch] = t;
+    *out = &c->chunks[ch];
+    return LF_OK;
+}
+
+int pick_src_chunk(const lf_ctx* c, int tiles) {
+    if (c->opt_src_chunk > 0) return (int)c->opt_src_chunk;
+    // enough workgroups to fill 256 CUs several times over, as few partials as that allows
+    const int64_t target_blocks = 4096;
+    int64_t ch = (c->N * (int64_t)tiles + target_blocks - 1) / target_blocks;
+    ch = ((ch + lf::BLOCK - 1) / lf::BLOCK) * lf::BLOCK;
+    return (int)std::min<int64_t>(std::max<int64_t>(ch, lf::BLOCK), 4096);
+}
+
+int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
+    if (Bpad > c->cap_B) {
+        int nb = std::max(Bpad, c->cap_B * 2);
+        LF_HIP(c, hipDeviceSynchronize());
+        hipFree(c->d_theta); hipFree(c->d_out); hipFree(c->d_outA); hipFree(c->d_outB);
+        hipFree(c->d_wrec); hipFree(c->d_prior);
+        if (c->h_theta) hipHostFree(c->h_theta);
+        if (c->h_out) hipHostFree(c->h_out);
+        c->cap_B = 0;
+        LF_HIP(c, hipMalloc((void**)&c->d_theta, (size_t)nb * 16 * sizeof(double)));
+        LF_HIP(c, hipMalloc((void**)&c->d_out, (size_t)nb * sizeof(double)));
+        LF_HIP(c, hipMalloc((void**)&c->d_outA, (size_t)nb * sizeof(double)));
+        LF_HIP(c, hipMalloc((void**)&c->d_outB, (size_t)nb * sizeof(double)));
+        LF_HIP(c, hipMalloc((void**)&c->d_wrec, (size_t)nb * lf::REC * sizeof(double)));
+        LF_HIP(c, hipMalloc((void**)&c->d_prior, (size_t)nb * sizeof(int)));
+        LF_HIP(c, hipHostMalloc((void**)&c->h_theta, (size_t)nb * 16 * sizeof(double), hipHostMallocDefault));
+        LF_HIP(c, hipHostMalloc((void**)&c->h_out, (size_t)nb * 3 * sizeof(double), hipHostMallocDefault));
+        c->cap_B = nb;
+    }
+    if (partA > c->cap_partA) {
+        LF_HIP(c, hipDeviceSynchronize());
+        hipFree(c->d_partA);
+        c->cap_partA = 0;
+        LF_HIP(c, hipMalloc((void**)&c->d_partA, partA * sizeof(double)));
+        c->cap_partA = partA;
+    }
+    if (partB > c->cap_partB) {
+        LF_HIP(c, hipDeviceSynchronize());
+        hipFree(c->d_partB);
+        c->cap_partB = 0;
+        LF_HIP(c, hipMalloc((void**)&c->d_partB, partB * sizeof(double)));
+        c->cap_partB = partB;
+    }
+    return LF_OK;
+}
+
+struct Prof {
+    lf_ctx* c;
+    hipStream_t s;
+    int kind;
+    EventPair ep{};
+    bool on;
+    Prof(lf_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling) {
+        if (on) {
+            hipEventCreate(&ep.a);
+            hipEventCreate(&ep.b);
+            ep.kind = kind;
+            hipEventRecord(ep.a, s);
+        }
+    }
+    ~Prof() {
+        if (on) {
+            hipEventRecord(ep.b, s);
+            c->events.push_back(ep);
+        }
+    }
+};
+
+// enqueue the four launches of one batched evaluation on `s`
+int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
+            hipStream_t s) {
+    using namespace lf;
+    const int tiles = (B + TW - 1) / TW;
+    const int Bpad = tiles * TW;
+    const int ch = pick_src_chunk(c, tiles);
+    ChunkTable* ct = nullptr;
+    int rc = get_chunks(c, ch, &ct);
+    if (rc != LF_OK) return rc;
+    const int nchA = ct->n;
+    const int nchB = (c->nnodes + BLOCK - 1) / BLOCK;
+    rc = ensure_workspace(c, Bpad, (size_t)Bpad * nchA, (size_t)Bpad * nchB);
+    if (rc != LF_OK) return rc;
+    // the workspace is shared by consecutive calls: order a stream switch behind the previous work
+    if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
+    c->last_stream = s;
+    c->any_enqueued = true;
+
+    {
+        Prof p(c, s, 0);
+        hipLaunchKernelGGL(lf_prepare, dim3((Bpad + 63) / 64), dim3(64), 0, s, c->kc, d_theta, B, Bpad,
+                           c->d_wrec, c->d_prior);
+    }
+    SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, ct->d_start, ct->d_len, ct->d_field};
+    NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->nnodes};
+    if (nchA > 0) {
+        Prof p(c, s, 1);
+        dim3 grid(nchA, tiles);
+        switch (c->kc.variant) {
+            case LF_FREE:
+                hipLaunchKernelGGL(lf_srcsum<LF_FREE>, grid, dim3(BLOCK), 0, s, c->kc, sa, c->d_wrec, c->d_partA, nchA);
+                break;
+            case LF_FIXCOMP:
+                hipLaunchKernelGGL(lf_srcsum<LF_FIXCOMP>, grid, dim3(BLOCK), 0, s, c->kc, sa, c->d_wrec, c->d_partA, nchA);
+                break;
+            default:
+                hipLaunchKernelGGL(lf_srcsum<LF_ZEVOL>, grid, dim3(BLOCK), 0, s, c->kc, sa, c->d_wrec, c->d_partA, nchA);
+        }
+    }
+    {
+        Prof p(c, s, 2);
+        dim3 grid(nchB, tiles);
+        switch (c->kc.variant) {
+            case LF_FREE:
+                hipLaunchKernelGGL(lf_gridsum<LF_FREE>, grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, c->d_partB, nchB);
+                break;
+            case LF_FIXCOMP:
+                hipLaunchKernelGGL(lf_gridsum<LF_FIXCOMP>, grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, c->d_partB, nchB);
+                break;
+            default:
+                hipLaunchKernelGGL(lf_gridsum<LF_ZEVOL>, grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, c->d_partB, nchB);
+        }
+    }
+    {
+        Prof p(c, s, 3);
+        hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
+                           c->d_prior, B, d_out, d_outA, d_outB);
+    }
+    LF_HIP(c, hipGetLastError());
+    return LF_OK;
+}
+
+void free_ctx(lf_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& e : c->events) {
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    for (auto& kv : c->chunks) {
+        hipFree(kv.second.d_start);
+        hipFree(kv.second.d_len);
+        hipFree(kv.second.d_field);
+    }
+    double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4,
+                      c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
+    for (double* b : bufs)
+        if (b) hipFree(b);
+    if (c->d_prior) hipFree(c->d_prior);
+    if (c->h_theta) hipHostFree(c->h_theta);
+    if (c->h_out) hipHostFree(c->h_out);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int build(lf_ctx* c, const lf_desc* d) {
+    using namespace lf;
+    const int nf = d->nf, S = d->S;
+    const int64_t N = d->N;
+    KConst& kc = c->kc;
+    kc.variant = d->variant;
+    kc.fix_sch_al = d->fix_sch_al ? 1 : 0;
+    kc.nf = nf;
+    kc.S = S;
+    if (d->variant == LF_FREE) kc.ndim = 2 + (kc.fix_sch_al ? 0 : 1) + nf + 1;
+    else if (d->variant == LF_FIXCOMP) kc.ndim = 2 + (kc.fix_sch_al ? 0 : 1);
+    else kc.ndim = 6 + (kc.fix_sch_al ? 0 : 1);
+    for (int f = 0; f < MAXF; ++f) {
+        kc.lnom0_src[f] = 0.0;
+        kc.om0_grid[f] = 0.0;
+        kc.flim0[f] = 0.0;
+    }
+    for (int f = 0; f < nf; ++f) {
+        // per-source term: Omega_0_arr is dtype=int (lumfuncmcmc.py:285) -> truncation toward zero
+        kc.lnom0_src[f] = std::log(std::trunc(d->omega0[f]) / LF_SQARCSEC);
+        kc.om0_grid[f] = d->omega0[f] / LF_SQARCSEC;           // integral: float (lumfuncmcmc.py:375)
+        if (d->flim0) kc.flim0[f] = d->flim0[f];
+    }
+    {
+        const double a = (2.0 * d->fcmin - 1.0) * (2.0 * d->fcmin - 1.0);   // VmaxLumFunc.py:164
+        kc.fc_ratio = std::fabs(a / (1.0 - a));
+    }
+    std::memcpy(kc.lims, d->lims, sizeof(kc.lims));
+    std::memcpy(kc.pivots, d->pivots, sizeof(kc.pivots));
+    kc.sch_al0 = d->sch_al0;
+    kc.alpha0 = d->alpha0;
+    c->N = N;
+    c->nnodes = S * S;
+    c->field_ind.assign(d->field_ind, d->field_ind + nf + 1);
+
+    // ---- per-source tables
+    std::vector<double> a1(N), P(N), U(N);
+    for (int64_t i = 0; i < N; ++i) {
+        const double lum = d->lum[i];
+        if (d->variant == LF_FREE) {
+            a1[i] = d->logf[i];
+            P[i] = std::pow(10.0, lum - LF_LREF);
+            U[i] = std::pow(10.0, d->logf[i] - LF_FREF);
+        } else if (d->variant == LF_FIXCOMP) {
+            a1[i] = std::log(d->om_arr[i]);
+            P[i] = std::pow(10.0, lum - LF_LREF);
+            U[i] = 0.0;
+        } else {
+            a1[i] = d->z[i];
+            P[i] = std::log(d->om_arr[i]);
+            U[i] = d->z[i] * d->z[i];
+        }
+    }
+    int rc;
+    if ((rc = upload(c, &c->d_lum, d->lum, (size_t)N)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_a1, a1.data(), (size_t)N)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_P, P.data(), (size_t)N)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_U, U.data(), (size_t)N)) != LF_OK) return rc;
+
+    // ---- grid-node tables.  trapz weights from the actual spacings (scipy trapz = sum d*(y1+y0)/2)
+    const size_t nn = (size_t)S * S;
+    std::vector<double> G(nn), PG(nn), W(nn), a3(nn, 0.0), a4(nn, 0.0), wz(S);
+    for (int k = 0; k < S; ++k) {
+        const double dl = k > 0 ? d->zarr[k] - d->zarr[k - 1] : 0.0;
+        const double dr = k < S - 1 ? d->zarr[k + 1] - d->zarr[k] : 0.0;
+        wz[k] = 0.5 * (dl + dr);
+    }
+    for (int j = 0; j < S; ++j) {
+        for (int k = 0; k < S; ++k) {
+            const size_t g = (size_t)j * S + k;
+            const double x = d->logL[g];
+            const double dl = j > 0 ? x - d->logL[g - S] : 0.0;
+            const double dr = j < S - 1 ? d->logL[g + S] - x : 0.0;
+            const double w = 0.5 * (dl + dr) * wz[k];
+            G[g] = x;
+            PG[g] = std::pow(10.0, x - LF_LREF);
+            if (d->variant == LF_FREE) {
+                const double dlcm = LF_MPC_CM * d->dl_zarr[k];
+                const double lf = x - std::log10(4.0 * M_PI * dlcm * dlcm);
+                a3[g] = lf;
+                a4[g] = std::pow(10.0, lf - LF_FREF);
+                W[g] = w * d->volume_part[k];
+            } else {
+                double s = 0.0;
+                for (int f = 0; f < nf; ++f) s += d->integ_part[(size_t)f * nn + g];
+                W[g] = w * s;
+                if (d->variant == LF_ZEVOL) {
+                    a3[g] = d->zarr[k];
+                    a4[g] = d->zarr[k] * d->zarr[k];
+                }
+            }
+        }
+    }
+    if ((rc = upload(c, &c->d_G, G.data(), nn)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_PG, PG.data(), nn)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_W, W.data(), nn)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_a3, a3.data(), nn)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_a4, a4.data(), nn)) != LF_OK) return rc;
+    LF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const int mb = d->max_batch > 0 ? d->max_batch : 1024;
+    const int tiles = (mb + TW - 1) / TW;
+    return ensure_workspace(c, tiles * TW, 0, 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lf_abi_version(void) { return LF_ABI_VERSION; }
+
+const char* lf_last_error(const lf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+lf_ctx* lf_create(const lf_desc* d) {
+    g_create_error.clear();
+    if (!d) {
+        g_create_error = "lf_create: NULL descriptor";
+        return nullptr;
+    }
+    auto bad = [&](const char* m) {
+        g_create_error = std::string("lf_create: ") + m;
+        return (lf_ctx*)nullptr;
+    };
+    if (d->variant < LF_FREE || d->variant > LF_ZEVOL) return bad("unknown variant");
+    if (d->nf < 1 || d->nf > LF_MAX_FIELDS) return bad("nf out of range (1..LF_MAX_FIELDS)");
+    if (d->S < 2 || d->S > 4096) return bad("S out of range");
+    if (d->N < 0 || d->N > 2000000000LL) return bad("N out of range");
+    if (!d->field_ind || !d->omega0 || !d->logL || !d->zarr) return bad("NULL field_ind/omega0/logL/zarr");
+    if (d->N > 0 && !d->lum) return bad("NULL lum");
+    if (d->field_ind[0] != 0 || d->field_ind[d->nf] != d->N) return bad("field_ind must span [0, N]");
+    for (int f = 0; f < d->nf; ++f)
+        if (d->field_ind[f + 1] < d->field_ind[f]) return bad("field_ind must be non-decreasing");
+    if (!(d->fcmin > 0.0 && d->fcmin < 1.0) || d->fcmin == 0.5) return bad("fcmin must be in (0,1), != 0.5");
+    if (d->variant == LF_FREE) {
+        if ((d->N > 0 && !d->logf) || !d->volume_part || !d->dl_zarr) return bad("FREE needs logf, volume_part, dl_zarr");
+    } else {
+        if ((d->N > 0 && !d->om_arr) || !d->integ_part) return bad("FIXCOMP/ZEVOL need om_arr, integ_part");
+        if (d->variant == LF_FIXCOMP && !d->flim0) return bad("FIXCOMP needs flim0");
+        if (d->variant == LF_ZEVOL && d->N > 0 && !d->z) return bad("ZEVOL needs z");
+        if (d->variant == LF_ZEVOL && (d->pivots[0] == d->pivots[1] || d->pivots[0] == d->pivots[2] ||
+                                       d->pivots[1] == d->pivots[2]))
+            return bad("ZEVOL pivots must be distinct");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad("no HIP device visible");
+    if (d->device < 0 || d->device >= ndev) return bad("device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) return bad("hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("lf_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return nullptr;
+    }
+    if (hipSetDevice(d->device) != hipSuccess) return bad("hipSetDevice failed");
+    lf_ctx* c = new (std::nothrow) lf_ctx();
+    if (!c) return bad("out of host memory");
+    c->device = d->device;
+    int rc = LF_OK;
+    try {
+        rc = build(c, d);
+    } catch (const std::bad_alloc&) {
+        c->err = "out of host memory";
+        rc = LF_ERR_NOMEM;
+    }
+    if (rc != LF_OK) {
+        g_create_error = "lf_create: " + c->err;
+        free_ctx(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void lf_destroy(lf_ctx* ctx) { free_ctx(ctx); }
+
+int lf_ndim(const lf_ctx* ctx) { return ctx ? ctx->kc.ndim : LF_ERR_ARG; }
+
+int lf_lnprob_batch_device(lf_ctx* c, const double* d_theta, int B, double* d_out, void* hip_stream) {
+    if (!c) return LF_ERR_ARG;
+    if (!d_theta || !d_out || B <= 0) {
+        c->err = "lf_lnprob_batch_device: NULL pointer or B <= 0";
+        return LF_ERR_ARG;
+    }
+    LF_HIP(c, hipSetDevice(c->device));
+    return enqueue(c, d_theta, B, d_out, nullptr, nullptr, (hipStream_t)hip_stream);
+}
+
+static int host_eval(lf_ctx* c, const double* theta, int B, double* out, double* outA, double* outB) {
+    using namespace lf;
+    if (!c) return LF_ERR_ARG;
+    if (!theta || B <= 0 || (!out && !(outA && outB))) {
+        c->err = "lf_lnprob_batch: NULL pointer or B <= 0";
+        return LF_ERR_ARG;
+    }
+    LF_HIP(c, hipSetDevice(c->device));
+    const int Bpad = ((B + TW - 1) / TW) * TW;
+    int rc = ensure_workspace(c, Bpad, 0, 0);
+    if (rc != LF_OK) return rc;
+    const size_t tb = (size_t)B * c->kc.ndim * sizeof(double);
+    std::memcpy(c->h_theta, theta, tb);
+    LF_HIP(c, hipMemcpyAsync(c->d_theta, c->h_theta, tb, hipMemcpyHostToDevice, c->stream));
+    rc = enqueue(c, c->d_theta, B, c->d_out, c->d_outA, c->d_outB, c->stream);
+    if (rc != LF_OK) return rc;
+    const size_t ob = (size_t)B * sizeof(double);
+    LF_HIP(c, hipMemcpyAsync(c->h_out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
+    if (outA) {
+        LF_HIP(c, hipMemcpyAsync(c->h_out + B, c->d_outA, ob, hipMemcpyDeviceToHost, c->stream));
+        LF_HIP(c, hipMemcpyAsync(c->h_out + 2 * (size_t)B, c->d_outB, ob, hipMemcpyDeviceToHost, c->stream));
+    }
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+    if (out) std::memcpy(out, c->h_out, ob);
+    if (outA) {
+        std::memcpy(outA, c->h_out + B, ob);
+        std::memcpy(outB, c->h_out + 2 * (size_t)B, ob);
+    }
+    return LF_OK;
+}
+
+int lf_lnprob_batch(lf_ctx* c, const double* theta, int B, double* out) {
+    if (c && !out) {
+        c->err = "lf_lnprob_batch: NULL out";
+        return LF_ERR_ARG;
+    }
+    return host_eval(c, theta, B, out, nullptr, nullptr);
+}
+
+int lf_lnprob_pieces(lf_ctx* c, const double* theta, int B, double* outA, double* outB) {
+    if (c && (!outA || !outB)) {
+        c->err = "lf_lnprob_pieces: NULL output";
+        return LF_ERR_ARG;
+    }
+    return host_eval(c, theta, B, nullptr, outA, outB);
+}
+
+int lf_set_profiling(lf_ctx* c, int enabled) {
+    if (!c) return LF_ERR_ARG;
+    c->profiling = enabled != 0;
+    return LF_OK;
+}
+
+int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
+    if (!c || !ms || !launches) return LF_ERR_ARG;
+    LF_HIP(c, hipSetDevice(c->device));
+    for (auto& e : c->events) {
+        LF_HIP(c, hipEventSynchronize(e.b));
+        float t = 0.f;
+        LF_HIP(c, hipEventElapsedTime(&t, e.a, e.b));
+        c->acc_ms[e.kind] += t;
+        c->acc_n[e.kind] += 1;
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    c->events.clear();
+    for (int i = 0; i < 4; ++i) {
+        ms[i] = c->acc_ms[i];
+        launches[i] = c->acc_n[i];
+        c->acc_ms[i] = 0;
+        c->acc_n[i] = 0;
+    }
+    return LF_OK;
+}
+
+int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return LF_ERR_ARG;
+    if (std::strcmp(key, "src_chunk") == 0) {
+        if (value < 0 || value % lf::BLOCK != 0 || value > (1 << 20)) {
+            c->err = "src_chunk must be a non-negative multiple of 256";
+            return LF_ERR_ARG;
+        }
+        c->opt_src_chunk = value;
+        return LF_OK;
+    }
+    c->err = std::string("unknown option ") + key;
+    return LF_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Parity of the HIP path (through the C ABI) with the reference: golden vectors recorded from
+the reference, the oracle on seeded inputs, size-independent properties at BASELINE sizes, and
+the edge cases.  All of it needs a real MI355X: `pytest -m gpu`.
+
+Tolerance: the kernels work in log space with hoisted factors (lf_kernels.h), the reference in
+linear space; per term they agree to a few ulp, and the stated fp64 tolerance on lnprob and on
+each piece is RTOL = 1e-12 relative (measured worst case is printed by each test)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from lf_testlib import O, compare_rows, make_inputs, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
+RTOL = 1e-12
+
+
+def ctx_of(inp, **kw):
+    from lumfuncmcmc_amd.capi import LFContext
+    return LFContext(inp, device=0, **kw)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_vectors(case):
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    inp = O.inputs_from_golden(g, case.split("_")[0])
+    ctx = ctx_of(inp)
+    th = g["theta"]
+    assert ctx.ndim == th.shape[1]
+    got = ctx.lnprob_batch(th)
+    w = compare_rows(got, g["lnprob"], inp, th, RTOL)
+    A, B = ctx.lnprob_pieces(th)
+    wa = compare_rows(A, g["A"], inp, th, RTOL, "A")
+    okB = np.isfinite(g["B"])
+    np.testing.assert_allclose(B[okB], g["B"][okB], rtol=RTOL, atol=0)
+    assert np.array_equal(np.isnan(A), np.isnan(g["A"]))      # NaN pieces exactly where the prior fails
+    # one row at a time (the reference's calling pattern) gives the same bits as the batch
+    one = np.array([ctx.lnprob_batch(t)[0] for t in th[:5]])
+    assert np.array_equal(one, got[:5])
+    print("%s worst rel lnprob %.2e A %.2e" % (case, w, wa))
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant,n,fsa", [("free", 20000, False), ("free", 4099, True),
+                                           ("fixcomp", 20000, False), ("zevol", 20000, False),
+                                           ("zevol", 7777, True)])
+def test_oracle_seeded(variant, n, fsa):
+    inp = make_inputs(variant, n, seed=123 + n, fix_sch_al=fsa, zslices=8 if variant == "zevol" else 0)
+    th = synth.walkers(variant, 37, seed=5, fix_sch_al=fsa)       # 37: not a multiple of the walker tile
+    ref, refA, refB = O.lnprob_batch(inp, th, pieces=True)
+    ctx = ctx_of(inp)
+    got = ctx.lnprob_batch(th)
+    w = compare_rows(got, ref, inp, th, RTOL)
+    A, B = ctx.lnprob_pieces(th)
+    np.testing.assert_allclose(A, refA, rtol=RTOL)
+    np.testing.assert_allclose(B, refB, rtol=RTOL)
+    print("%s n=%d worst rel %.2e" % (variant, n, w))
+    ctx.close()
+
+
+def test_batch_shapes_and_growth():
+    inp = make_inputs("free", 3000, seed=9)
+    ctx = ctx_of(inp, max_batch=8)
+    th = synth.walkers("free", 700, seed=11)
+    full = ctx.lnprob_batch(th)                  # grows the workspace past max_batch
+    for b in (1, 7, 8, 9, 64, 129):
+        assert np.array_equal(ctx.lnprob_batch(th[:b]), full[:b])
+    ref = O.lnprob_batch(inp, th[:12])
+    np.testing.assert_allclose(full[:12], ref, rtol=RTOL)
+    assert ctx.lnprob_batch(np.empty((0, ctx.ndim))).shape == (0,)
+    with pytest.raises(ValueError):
+        ctx.lnprob_batch(np.zeros((3, ctx.ndim + 1)))
+    ctx.close()
+
+
+def test_prior_and_nan_rows():
+    inp = make_inputs("free", 1000, seed=2)
+    ctx = ctx_of(inp)
+    th = synth.walkers("free", 9, seed=3)
+    th[1, 0] = 45.0 + 1e-9        # outside
+    th[2, 8] = np.nan             # NaN never passes a comparison -> -inf, never NaN out
+    th[3, 3] = 1.0                # inclusive edge stays finite
+    th[4, :] = np.inf
+    out = ctx.lnprob_batch(th)
+    assert out[1] == -np.inf and out[2] == -np.inf and out[4] == -np.inf
+    assert np.isfinite(out[[0, 3, 5, 6, 7, 8]]).all()
+    assert not np.isnan(out).any()
+    allbad = np.full((5, ctx.ndim), 99.0)
+    assert (ctx.lnprob_batch(allbad) == -np.inf).all()
+    ctx.close()
+
+
+def test_underflow_convention():
+    """log(product) = -inf as soon as one source's linear-space product is 0 (App. B-5)."""
+    inp = make_inputs("fixcomp", 5000, seed=4)
+    ctx = ctx_of(inp)
+    th = np.array([[ls, -2.0, -1.49] for ls in np.linspace(40.0, 41.2, 49)])
+    ref = O.lnprob_batch(inp, th)
+    got = ctx.lnprob_batch(th)
+    assert np.isinf(ref).any() and np.isfinite(ref).any()
+    compare_rows(got, ref, inp, th, RTOL)
+    ctx.close()
+
+
+def test_ragged_and_empty_fields():
+    inp = make_inputs("free", 2000, seed=6)
+    inp["field_ind"] = np.array([0, 0, 3, 1200, 1200, 2000], dtype=np.int64)   # two empty fields, one of 3
+    th = synth.walkers("free", 10, seed=7)
+    ref = O.lnprob_batch(inp, th)
+    ctx = ctx_of(inp)
+    np.testing.assert_allclose(ctx.lnprob_batch(th), ref, rtol=RTOL)
+    ctx.close()
+    for n in (1, 5):
+        inp = make_inputs("zevol", n, seed=8)
+        th = synth.walkers("zevol", 4, seed=7)
+        ctx = ctx_of(inp)
+        np.testing.assert_allclose(ctx.lnprob_batch(th), O.lnprob_batch(inp, th), rtol=RTOL)
+        ctx.close()
+    # empty catalogue: lnlike = -integral
+    inp = make_inputs("fixcomp", 0, seed=8)
+    th = synth.walkers("fixcomp", 4, seed=7)
+    ctx = ctx_of(inp)
+    A, B = ctx.lnprob_pieces(th)
+    assert (A == 0).all()
+    np.testing.assert_allclose(ctx.lnprob_batch(th), -B, rtol=0)
+    np.testing.assert_allclose(B, [O.piece_b(inp, O.split_theta(inp, t)) for t in th], rtol=RTOL)
+    ctx.close()
+
+
+def test_more_fields_and_other_grid_sizes():
+    inp = make_inputs("free", 4000, seed=10, nf=8, S=37)
+    th = synth.walkers("free", 6, seed=7, nf=8)
+    ctx = ctx_of(inp)
+    assert ctx.ndim == 12
+    np.testing.assert_allclose(ctx.lnprob_batch(th), O.lnprob_batch(inp, th), rtol=RTOL)
+    ctx.close()
+    inp = make_inputs("fixcomp", 900, seed=10, nf=1, S=64)
+    th = synth.walkers("fixcomp", 6, seed=7)
+    ctx = ctx_of(inp)
+    np.testing.assert_allclose(ctx.lnprob_batch(th), O.lnprob_batch(inp, th), rtol=RTOL)
+    ctx.close()
+
+
+def test_chunking_does_not_change_results():
+    inp = make_inputs("free", 50000, seed=12)
+    th = synth.walkers("free", 16, seed=13)
+    ctx = ctx_of(inp)
+    base = ctx.lnprob_batch(th)
+    assert np.array_equal(base, ctx.lnprob_batch(th))            # bitwise reproducible
+    for ch in (256, 1024, 4096):
+        ctx.set_option("src_chunk", ch)
+        np.testing.assert_allclose(ctx.lnprob_batch(th), base, rtol=1e-14)
+    ctx.close()
+
+
+def test_device_pointer_entry_matches_host_entry():
+    import torch
+    inp = make_inputs("zevol", 10000, seed=14, zslices=8)
+    th = synth.walkers("zevol", 33, seed=15)
+    ctx = ctx_of(inp)
+    host = ctx.lnprob_batch(th)
+    dth = torch.from_numpy(th).cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out = ctx.lnprob_torch(dth)
+    side.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host)
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant,n,W", [("free", 1000000, 256), ("fixcomp", 1000000, 256),
+                                         ("zevol", 800000, 512)])
+def test_full_size_properties(variant, n, W):
+    """BASELINE sizes, where the scalar oracle is too slow to sweep: size-independent properties.
+    (1) phi* shift: A moves by N ln10 d, B scales by 10^d.  (2) catalogue additivity: A over the
+    whole catalogue = sum of A over two halves (different launch geometry).  (3) a handful of rows
+    against the oracle.  (4) FIXCOMP: the closed form of SURVEY App. A.4."""
+    inp = make_inputs(variant, n, zslices=8 if variant == "zevol" else 0)
+    B = W // 2
+    th = synth.walkers(variant, B, seed=1)
+    ctx = ctx_of(inp)
+    A, Bi = ctx.lnprob_pieces(th)
+    lnp = ctx.lnprob_batch(th)
+    assert np.isfinite(lnp).all()
+    np.testing.assert_allclose(lnp, A - Bi, rtol=1e-15)
+    d = 0.37
+    th2 = th.copy()
+    if variant == "zevol":
+        th2[:, 3:6] += d
+    else:
+        th2[:, 1] += d
+    A2, B2 = ctx.lnprob_pieces(th2)
+    np.testing.assert_allclose(A2 - A, n * np.log(10.0) * d, rtol=1e-11)
+    np.testing.assert_allclose(B2 / Bi, 10.0 ** d, rtol=1e-12)
+    ref = O.lnprob_batch(inp, th[:3])
+    np.testing.assert_allclose(lnp[:3], ref, rtol=RTOL)
+    ctx.close()
+    # additivity over a split of every field in two
+    fi = inp["field_ind"]
+    halves = []
+    for part in (0, 1):
+        sel = np.concatenate([np.arange(fi[f], fi[f + 1])[part::2] for f in range(len(fi) - 1)])
+        sub = dict(inp)
+        for k in ("lum", "z", "DLz", "Om_arr"):
+            sub[k] = inp[k][sel]
+        sub["field_ind"] = np.concatenate([[0], np.cumsum([len(np.arange(fi[f], fi[f + 1])[part::2])
+                                                            for f in range(len(fi) - 1)])]).astype(np.int64)
+        c2 = ctx_of(sub)
+        halves.append(c2.lnprob_pieces(th)[0])
+        c2.close()
+    np.testing.assert_allclose(halves[0] + halves[1], A, rtol=1e-13)
+    if variant == "fixcomp":
+        lum = inp["lum"]
+        c1 = np.log(10.0) * (th[:, 2] + 1)
+        cf = (n * (np.log(np.log(10.0)) + np.log(10.0) * th[:, 1]) + c1 * (lum.sum() - n * th[:, 0])
+              - 10.0 ** (-th[:, 0]) * np.sum(10.0 ** lum) + np.log(inp["Om_arr"]).sum())
+        np.testing.assert_allclose(A, cf, rtol=1e-12)

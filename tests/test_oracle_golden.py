@@ -1,0 +1,87 @@
+"""The NumPy oracle (oracle/lf_oracle.py) against vectors recorded from the reference itself
+(oracle/gen_golden.py ran /root/reference under numpy 1.26.4 / scipy 1.7.1 / astropy 4.3.1)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lf_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+# libm differences between the recording interpreter and this one are a few ulp per term
+RTOL = 5e-15
+
+
+def test_fixture_set_is_complete():
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        man = json.load(f)
+    assert sorted(man) == CASES
+    assert {c.split("_")[0] for c in CASES} == {"free", "fixcomp", "zevol"}
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference(case):
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    inp = O.inputs_from_golden(g, case.split("_")[0])
+    lnp, A, B = O.lnprob_batch(inp, g["theta"], pieces=True)
+    ref = g["lnprob"]
+    assert not np.isnan(ref).any()
+    # identical -inf pattern: prior failures and likelihood underflow
+    assert np.array_equal(np.isinf(lnp), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert fin.sum() >= 8
+    np.testing.assert_allclose(lnp[fin], ref[fin], rtol=RTOL, atol=0)
+    okA = np.isfinite(g["A"])
+    np.testing.assert_allclose(A[okA], g["A"][okA], rtol=RTOL, atol=0)
+    okB = np.isfinite(g["B"])
+    np.testing.assert_allclose(B[okB], g["B"][okB], rtol=RTOL, atol=0)
+    # rows that failed the prior recorded NaN pieces; the oracle reports the same rows
+    assert np.array_equal(np.isnan(A), np.isnan(g["A"]))
+
+
+def test_known_answer_survey_appendix_c():
+    """N=1e3, default_rng(0), configLF theta0 -> -46587.950223002365."""
+    g = np.load(os.path.join(GOLDEN, "free_n1000.npz"))
+    inp = O.inputs_from_golden(g, "free")
+    th0 = [42.5, -2.0, -1.49, 2.72, 3.61, 2.55, 3.31, 3.30, 4.56]
+    r, A, B = O.lnprob(inp, th0, pieces=True)
+    assert abs(r - (-46587.950223002365)) < 1e-9
+    assert abs(A - (-18410.472602)) < 1e-5 and abs(B - 28177.477621) < 1e-5
+
+
+def test_fleming_known_values():
+    with open(os.path.join(GOLDEN, "cosmo_known.json")) as f:
+        k = json.load(f)
+    f_ = np.array(k["fleming_f"])
+    # fc ** (1/decay) with exponents of several hundred amplifies a 1-ulp libm difference in fc
+    # to ~1e-12 relative on values of 1e-70: compare the faint end in log space
+    for key, args in (("fleming_Flim2.72e-17_a4.56_fc0.1", (2.72e-17, 4.56, 0.1)),
+                      ("fleming_Flim3.3e-17_a2.0_fc0.1", (3.3e-17, 2.0, 0.1))):
+        got, ref = O.fleming(f_, *args), np.array(k[key])
+        np.testing.assert_allclose(np.log(got), np.log(ref), rtol=1e-13, atol=1e-13)
+        big = ref > 1e-6
+        np.testing.assert_allclose(got[big], ref[big], rtol=1e-13)
+    assert abs(O.inverse_fleming(2.72e-17, 4.56) / k["inverse_fleming_2.72e-17_4.56"] - 1) < 1e-15
+    assert abs(O.SQARCSEC / k["sqarcsec"] - 1) < 1e-16
+
+
+def test_prior_edges():
+    g = np.load(os.path.join(GOLDEN, "zevol_n1000.npz"))
+    inp = O.inputs_from_golden(g, "zevol")
+    base = np.array([42.4, 42.5, 42.6, -2.1, -2.0, -1.9, -1.49])
+    assert np.isfinite(O.lnprob(inp, base))
+    e = base.copy(); e[0] = 45.0          # strict for L (lumfuncmcmc_z.py:355)
+    assert O.lnprob(inp, e) == -np.inf
+    e = base.copy(); e[6] = 1.0           # inclusive for alpha (:351)
+    assert np.isfinite(O.lnprob(inp, e))
+    g = np.load(os.path.join(GOLDEN, "free_n50.npz"))
+    inp = O.inputs_from_golden(g, "free")
+    b = np.array([42.5, -2.0, -1.49, 2.72, 3.61, 2.55, 3.31, 3.30, 4.56])
+    e = b.copy(); e[0] = 45.0             # inclusive (lumfuncmcmc.py:353)
+    assert np.isfinite(O.lnprob(inp, e))
+    e = b.copy(); e[8] = 7.0 + 1e-12
+    assert O.lnprob(inp, e) == -np.inf
