@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py - walker-lnprob evaluations per second of the HIP path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): the configuration the metric is quoted on - 10^6 synthetic sources,
+256 walkers, single-Schechter model with free completeness (LumFuncMCMC.lnprob, the drivers'
+default), fp64.  A step is one ensemble step: two half-ensemble calls of 128 theta rows each
+(what emcee's stretch move issues), i.e. 256 walker-lnprob evaluations over the whole catalogue.
+With N GPUs the walkers are sharded: every rank evaluates its own 256 walkers per step (weak
+scaling: 256 N walkers in all) and each half-step ends with the RCCL all-gather of the
+per-walker lnprob.  Catalogue, grids and theta blocks are resident in HBM before the timed
+region.  One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 (spec; half of the 157.3 fp32 figure)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+# nominal fp64 flops per (walker, source) term of the factored FREE formulation, with the op
+# weights of SURVEY.md section 8d (exp/log 40, rsqrt/div 16, other VALU 2 per FMA-class op):
+# 1 log + 1 exp + 1 rsqrt + 1 div + 17 mul/add/fma  
+FLOPS_PER_TERM = {"free": 40 + 40 + 16 + 16 + 2 * 17, "fixcomp": 2 * 6, "zevol": 40 + 2 * 14}
+BYTES_PER_SOURCE = {"free": 16, "fixcomp": 8, "zevol": 16}
+
+
+def build_model(variant, nsrc, walkers, device):
+    from lumfuncmcmc_amd import synth
+    from lumfuncmcmc_amd.model import LumFuncMCMC, LumFuncMCMCz
+    cat = synth.catalogue(nsrc, seed=20241016, zslices=8 if variant == "zevol" else 0)
+    fi = cat["field_ind"]
+    kw = dict(lum=synth.split_fields(cat["lum"], fi), lum_e=synth.split_fields(cat["lum_e"], fi),
+              Flim=list(synth.FLIM), alpha=synth.ALPHA_C, Omega_0=list(synth.OMEGA_0), sch_al=synth.SCH_AL,
+              sch_al_lims=synth.SCH_AL_LIMS, Lstar=synth.LSTAR, Lstar_lims=synth.LSTAR_LIMS,
+              phistar=synth.PHISTAR, phistar_lims=synth.PHISTAR_LIMS, Lc=synth.LC, Lh=synth.LH,
+              nwalkers=walkers, nsteps=1, min_comp_frac=synth.MIN_COMP_FRAC, field_ind=fi, device=device)
+    zs = synth.split_fields(cat["z"], fi)
+    if variant == "zevol":
+        return LumFuncMCMCz(zs, **kw)
+    return LumFuncMCMC(zs, fix_comp=(variant == "fixcomp"), Flim_lims=synth.FLIM_LIMS,
+                       alpha_lims=synth.ALPHA_LIMS, **kw)
+
+
+def cpu_baseline(model, variant, theta, budget_s=20.0):
+    """The NumPy port (oracle/lf_oracle.py) on this host, one thread, one theta row per call -
+    the reference's execution model under emcee.  Bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lf_oracle as O
+    inp = model.kernel_inputs()
+    inp["lims"] = {k: list(v) for k, v in inp["lims"].items()}
+    n, t0, vals = 0, time.perf_counter(), []
+    while n < 2 or time.perf_counter() - t0 < budget_s:     # cycle over the block until the budget is spent
+        v = O.lnprob(inp, theta[n % len(theta)])
+        if n < len(theta):
+            vals.append(v)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "walker-lnprob evals/s", "cores": 1, "kind": "port",
+            "sample": "%d evaluations cycling over the theta rows of the timed workload, %.1f s, single-thread NumPy scalar loop "
+                      "(DL(z_i) hoisted out of the call, which the reference does not do)" % (n, dt)}, np.array(vals)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--variant", default="free", choices=["free", "fixcomp", "zevol"])
+    ap.add_argument("--nsrc", type=int, default=1000000)
+    ap.add_argument("--walkers", type=int, default=256, help="walkers per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--src-chunk", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from lumfuncmcmc_amd.dist import ShardedLnProb
+    W = args.walkers                       # per GPU
+    half = W // 2
+    model = build_model(args.variant, args.nsrc, W * world, local)
+    ctx = model.context()
+    if args.src_chunk:
+        ctx.set_option("src_chunk", args.src_chunk)
+    ndim = ctx.ndim
+    from lumfuncmcmc_amd import synth
+    # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
+    nblk = 8
+    theta_all = synth.walkers(args.variant, half * world * nblk, seed=1).reshape(nblk, half * world, ndim)
+    blocks = [torch.from_numpy(theta_all[i]).to(dev) for i in range(nblk)]
+    sharded = ShardedLnProb(ctx.lnprob_torch, ndim, dev)
+
+    def step(i):
+        a = sharded.evaluate_tensor(blocks[(2 * i) % nblk])
+        b = sharded.evaluate_tensor(blocks[(2 * i + 1) % nblk])
+        return a, b
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    fence()
+    ctx.kernel_times()                      # clear
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    kt = ctx.kernel_times()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), "non-finite lnprob in the timed workload"
+
+    evals = W * world * args.steps
+    value = evals / dt
+    if rank == 0:
+        # dominant kernel = the per-source sum (piece A); one launch = one half-ensemble call on this GPU
+        k = kt["srcsum"]
+        launches = max(k["launches"], 1)
+        avg_ms = k["ms"] / launches
+        terms = float(args.nsrc) * half                                   # (walker, source) terms per launch
+        alg_flops = terms * FLOPS_PER_TERM[args.variant]
+        alg_bytes = args.nsrc * BYTES_PER_SOURCE[args.variant] + half * 8 * (ndim + 1)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("%s_n%d_b%d" % (args.variant, args.nsrc, half), {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12
+        ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "valu_fp64", "kernel": "lf_srcsum<%s>" % args.variant, "achieved": ach_tf,
+                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
+                    "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
+                    "terms_per_launch": terms, "flops_per_term_nominal": FLOPS_PER_TERM[args.variant],
+                    "terms_per_s": terms / (avg_ms * 1e-3),
+                    "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
+                    "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items()}}
+        res = {"metric": "walker-lnprob evals/sec (10^6 sources, 256 walkers)", "value": value,
+               "unit": "walker-lnprob evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "%s completeness, single Schechter: %d synthetic sources, %d walkers per GPU "
+                                      "(%d in all), 2 half-ensemble calls of %d theta rows per step"
+                                      % (args.variant, args.nsrc, W, W * world, half),
+                          "n_sources": args.nsrc, "walkers_per_gpu": W, "variant": args.variant,
+                          "parallelism": "walker-sharded x%d, RCCL all-gather of lnprob" % world},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref = cpu_baseline(model, args.variant, theta_all[(2 * (args.steps - 1)) % nblk], args.cpu_budget)
+            got = out[0].cpu().numpy()[:len(ref)]
+            cb["max_rel_diff_gpu_vs_port"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
+            res["cpu_baseline"] = cb
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,14 @@ def load():
         raise RuntimeError(
             "liblfmcmc.so not found at %s: the HIP library has not been built "
             "(run `python -m lumfuncmcmc_amd.build`). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64,
+    # and a second runtime initialised in the same process sees no GPU.  Importing torch first
+    # makes the dynamic loader resolve this library's libamdhip64.so.7 to torch's copy, so device
+    # pointers and streams can be shared with torch (and with RCCL through torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:

@@ -42,6 +42,16 @@ struct KConst {
     double flim0[MAXF];
 };
 
+// getQuadCoef, lumfuncmcmc_z.py:40-42, with the reference's operation order and no FMA contraction
+__device__ inline void quad_coef(double y1, double y2, double y3, double z1, double z2, double z3,
+                                 double& a, double& b, double& c) {
+#pragma clang fp contract(off)
+    const double z1s = z1 * z1, z2s = z2 * z2, z3s = z3 * z3;
+    a = ((y3 - y1) + (y2 - y1) * (z1 - z3) / (z2 - z1)) / (z3s - z1s + (z2s - z1s) * (z1 - z3) / (z2 - z1));
+    b = (y2 - y1 - a * (z2s - z1s)) / (z2 - z1);
+    c = y1 - a * z1s - b * z1;
+}
+
 // ----------------------------------------------------------------------------------------------
 // prepare: theta rows -> walker records + prior flag.  One thread per (padded) walker.
 // set_parameters_from_list + lnprior: lumfuncmcmc.py:327-358, lumfuncmcmc_z.py:339-362.
@@ -66,13 +76,9 @@ __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B, i
         }
         double z1 = kc.pivots[0], z2 = kc.pivots[1], z3 = kc.pivots[2];
         // getQuadCoef, lumfuncmcmc_z.py:40-42
-        double den = (z3 * z3 - z1 * z1 + (z2 * z2 - z1 * z1) * (z1 - z3) / (z2 - z1));
-        double aL = ((L3 - L1) + (L2 - L1) * (z1 - z3) / (z2 - z1)) / den;
-        double bL = (L2 - L1 - aL * (z2 * z2 - z1 * z1)) / (z2 - z1);
-        double cL = L1 - aL * z1 * z1 - bL * z1;
-        double aP = ((p3 - p1) + (p2 - p1) * (z1 - z3) / (z2 - z1)) / den;
-        double bP = (p2 - p1 - aP * (z2 * z2 - z1 * z1)) / (z2 - z1);
-        double cP = p1 - aP * z1 * z1 - bP * z1;
+        double aL, bL, cL, aP, bP, cP;
+        quad_coef(L1, L2, L3, z1, z2, z3, aL, bL, cL);
+        quad_coef(p1, p2, p3, z1, z2, z3, aP, bP, cP);
         r[Z_AL] = aL; r[Z_BL] = bL; r[Z_CL] = cL;
         r[Z_AP] = aP; r[Z_BP] = bP; r[Z_CP] = cP;
         r[Z_C1] = LF_LN10 * (al + 1.0);
@@ -114,6 +120,12 @@ __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B, i
 // ----------------------------------------------------------------------------------------------
 // shared pieces
 // ----------------------------------------------------------------------------------------------
+// a z^2 + b z + c with the reference's roundings (lumfuncmcmc_z.py:65-66): with close pivots the
+// three terms cancel by two or three digits, so an FMA-contracted form drifts by ~1e-13 relative.
+__device__ __forceinline__ double quad_nofma(double a, double b, double c, double z, double z2) {
+    return __dadd_rn(__dadd_rn(__dmul_rn(a, z2), __dmul_rn(b, z)), c);
+}
+
 // ln of the Fleming completeness fc = 1/2 (1 + num / sqrt(1 + num^2)), VmaxLumFunc.py:118-120
 __device__ __forceinline__ double ln_fc(double num) {
     double s = fma(num, num, 1.0);
@@ -205,8 +217,8 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa,
 #pragma unroll
             for (int w = 0; w < TW; ++w) {
                 const double* r = wr + w * REC;
-                const double Ls = r[Z_AL] * z2 + r[Z_BL] * z + r[Z_CL];      // lumfuncmcmc_z.py:66
-                const double ph = r[Z_AP] * z2 + r[Z_BP] * z + r[Z_CP];      // :65
+                const double Ls = quad_nofma(r[Z_AL], r[Z_BL], r[Z_CL], z, z2);   // lumfuncmcmc_z.py:66
+                const double ph = quad_nofma(r[Z_AP], r[Z_BP], r[Z_CP], z, z2);   // :65
                 const double t = lum - Ls;
                 const double v = dexp(LF_LN10 * t);
                 const double lnT = fma(r[Z_C1], t, fma(LF_LN10, ph, LF_LNLN10)) - v;
@@ -272,8 +284,8 @@ __global__ __launch_bounds__(BLOCK) void lf_gridsum(KConst kc, NodeArrays na,
 #pragma unroll
             for (int w = 0; w < TW; ++w) {
                 const double* r = wr + w * REC;
-                const double Ls = r[Z_AL] * z2 + r[Z_BL] * z + r[Z_CL];
-                const double ph = r[Z_AP] * z2 + r[Z_BP] * z + r[Z_CP];
+                const double Ls = quad_nofma(r[Z_AL], r[Z_BL], r[Z_CL], z, z2);
+                const double ph = quad_nofma(r[Z_AP], r[Z_BP], r[Z_CP], z, z2);
                 const double t = G - Ls;
                 const double lnT = fma(r[Z_C1], t, fma(LF_LN10, ph, LF_LNLN10)) - dexp(LF_LN10 * t);
                 acc[w] = fma(W, dexp(lnT), acc[w]);

@@ -1,0 +1,487 @@
+"""LumFuncMCMC / LumFuncMCMCz: the reference's class surface over the HIP boundary.
+
+Constructor keywords, attribute names and method names are those of the reference
+(lumfuncmcmc.py:73-79, lumfuncmcmc_z.py:119-125) so that its drivers
+(run_lumfuncmcmc.py:245-256, run_lumfuncmcmc_z.py:218-229) construct these classes unchanged.
+What differs is underneath: setup comes from hostsetup.py (own cosmology, no astropy), and
+`lnprob` / `lnprob_fix_comp` do not evaluate anything in Python - they hand theta to
+liblfmcmc.so (one row, or a whole half-ensemble at once) and return what the GPU computed.
+There is no NumPy fallback: without the library or a GPU the call raises.
+"""
+import logging
+import time
+
+import numpy as np
+
+from . import hostsetup as hs
+from .capi import LFContext
+from .sampler import EnsembleSampler
+
+TrueLumFunc = hs.true_lum_func       # module-level names the reference exports (lumfuncmcmc.py:25)
+schechter_z = hs.schechter_z         # lumfuncmcmc_z.py:45
+getQuadCoef = hs.get_quad_coef       # lumfuncmcmc_z.py:26
+Omega = hs.omega                     # lumfuncmcmc.py:47
+
+
+class _Base(object):
+    """State and behaviour shared by the two model classes."""
+
+    _logger_name = 'lumfuncmcmc'
+    device = 0
+
+    # ------------------------------------------------------------------ setup (host, once)
+    def _common_init(self, z, flux, flux_e, lum, lum_e):
+        self.z = np.concatenate(z)
+        self.zmin, self.zmax = min(self.z), max(self.z)
+        self._ctx, self._ctx_key = None, None
+        self.lnprob_fn = None          # optional override (lumfuncmcmc_amd.dist.ShardedLnProb)
+
+    def setDLdVdz(self):
+        """lumfuncmcmc.py:180-202."""
+        t = hs.distance_tables(self.z)
+        self.DL, self.DLf, self.dVdzf = t["DL"], t["DLf"], t["dVdzf"]
+        self._zint, self._DLarr = t["zint"], t["DLarr"]
+        roots = self._setup_roots()
+        self.minlumf = []
+        for ii in range(self.nfields):
+            if self.min_comp_frac <= 0.001:
+                minlum = np.zeros_like(self._DLarr)
+            else:
+                minlum = np.log10(4.0 * np.pi * (self._DLarr * hs.MPC_CM) ** 2 * roots[ii])
+            self.minlumf.append(hs.LinearInterp(self._zint, minlum))
+
+    def _fluxes_and_lums(self, flux, flux_e, lum, lum_e):
+        """lumfuncmcmc.py:165-173."""
+        if flux is not None:
+            self.flux = 1.0e-17 * np.concatenate(flux)
+            self.flux_e = 1.0e-17 * np.concatenate(flux_e) if flux_e is not None else None
+        else:
+            self.lum, self.lum_e = np.concatenate(lum), np.concatenate(lum_e)
+            self.getFluxes()
+        if lum is None:
+            self.getLumin()
+
+    def getLumin(self):
+        self.lum, self.lum_e = hs.lum_from_flux(self.flux, self.flux_e, self.DL)
+
+    def getFluxes(self):
+        self.flux, self.flux_e = hs.flux_from_lum(self.lum, self.lum_e, self.DL)
+
+    def defineFlimOmArr(self):
+        self.Flims_arr, self.Omega_0_arr = hs.field_arrays(self.Flim, self.Omega_0, self.field_ind)
+
+    def getFlim(self):
+        for ii in range(self.nfields):
+            self.Flims_arr[self.field_ind[ii]:self.field_ind[ii + 1]] = self.Flim[ii]
+
+    def setOmegaLz(self, size=501):
+        """lumfuncmcmc.py:204-215.  Only the fixed-completeness likelihoods read these splines, so
+        the free-completeness class builds them on first use."""
+        self._Omegaf = hs.omega_splines(self.DLf, self.zmin, self.zmax, self.Lc, self.Lh, self.Omega_0,
+                                        self.Flim, self.alpha, self.fcmin, size=size)
+
+    @property
+    def Omegaf(self):
+        if getattr(self, "_Omegaf", None) is None:
+            self.setOmegaLz()
+        return self._Omegaf
+
+    def setlnsimple(self, need_integ=True):
+        """lumfuncmcmc.py:217-235."""
+        g = hs.integration_grid(self.size_ln, self.zmin, self.zmax, np.min(self.lum), self.Lh, self.DLf,
+                                self.dVdzf, self.minlumf, self.Omegaf if need_integ else None)
+        self.zarr, self.DL_zarr, self.volume_part = g["zarr"], g["DL_zarr"], g["volume_part"]
+        self.zarr_rep, self.logL = g["zarr_rep"], g["logL"]
+        self.logLi = self.logL[-1]
+        self._integ_part = g["integ_part"]
+        self.Om_arr = hs.omega(self.lum, self.z, self.DLf, self.Omega_0_arr, 1.0e-17 * self.Flims_arr,
+                               self.alpha, self.fcmin)
+        self._DLz = self.DLf(self.z)
+
+    @property
+    def integ_part(self):
+        if self._integ_part is None:
+            self._integ_part = [self.volume_part * self.Omegaf[ii].ev(self.logL[ii], self.zarr_rep)
+                                for ii in range(self.nfields)]
+        return self._integ_part
+
+    def setup_logging(self):
+        self.log = logging.getLogger(self._logger_name)
+        if not len(self.log.handlers):
+            handler = logging.StreamHandler()
+            handler.setFormatter(logging.Formatter('[%(levelname)s - %(asctime)s] %(message)s'))
+            handler.setLevel(logging.INFO)
+            self.log.setLevel(logging.DEBUG)
+            self.log.addHandler(handler)
+
+    # ------------------------------------------------------------------ the boundary
+    def _variant(self):
+        raise NotImplementedError
+
+    def _lims(self):
+        return {"Lstar": self.Lstar_lims, "phistar": self.phistar_lims, "sch_al": self.sch_al_lims,
+                "Flim": getattr(self, "Flim_lims", [1.0, 6.0]), "alpha": getattr(self, "alpha_lims", [1.0, 7.0])}
+
+    def kernel_inputs(self):
+        """The arrays the C ABI takes (include/lfmcmc.h), under the reference's attribute names."""
+        v = self._variant()
+        inp = {"variant": v, "fix_sch_al": bool(self.fix_sch_al), "sch_al0": float(self.sch_al),
+               "field_ind": np.asarray(self.field_ind, dtype=np.int64), "lum": self.lum, "z": self.z,
+               "DLz": self._DLz, "Omega_0": np.asarray(self.Omega_0, dtype=np.float64),
+               "Om_arr": self.Om_arr, "Flim0": np.asarray(self._Flim0, dtype=np.float64),
+               "alpha0": float(self._alpha0), "logL": self.logL[-1], "zarr": self.zarr,
+               "DL_zarr": self.DL_zarr, "volume_part": self.volume_part, "fcmin": self.fcmin,
+               "lims": self._lims(), "pivots": (getattr(self, "z1", 1.2), getattr(self, "z2", 1.53),
+                                                getattr(self, "z3", 1.86)),
+               "integ_part": None}
+        if v != "free":
+            inp["integ_part"] = np.array(self.integ_part)
+        return inp
+
+    def context(self):
+        """The device context for the current (variant, fixed-parameter) configuration."""
+        key = (self._variant(), bool(self.fix_sch_al), float(self.sch_al) if self.fix_sch_al else None)
+        if self._ctx is None or self._ctx_key != key:
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = LFContext(self.kernel_inputs(), device=self.device,
+                                  max_batch=max(8, getattr(self, "nwalkers", 100) // 2))
+            self._ctx_key = key
+        return self._ctx
+
+    def _evaluate(self, theta):
+        th = np.asarray(theta, dtype=np.float64)
+        scalar = th.ndim == 1
+        if self.lnprob_fn is not None:
+            out = np.asarray(self.lnprob_fn(np.atleast_2d(th)))
+        else:
+            out = self.context().lnprob_batch(th)
+        return float(out[0]) if scalar else out
+
+    # ------------------------------------------------------------------ sampling
+    def _theta_lims(self):
+        raise NotImplementedError
+
+    def get_init_walker_values(self, num=None):
+        """Uniform in the prior box from numpy's global state (lumfuncmcmc.py:426-446)."""
+        lims = self._theta_lims()
+        if num is None:
+            num = self.nwalkers
+        if getattr(self, "diff_rand", True):
+            u = np.random.rand(num, len(lims))
+        else:
+            u = np.random.rand(num)[:, np.newaxis]
+        return u * (lims[:, 1] - lims[:, 0]) + lims[:, 0]
+
+    def _lnprob_name(self):
+        return 'lnprob'
+
+    def fit_model(self):
+        """Run the ensemble sampler on the batched boundary and collect `self.samples`
+        (lumfuncmcmc.py:479-513): same log lines, burn-in = min(int(3 tau), nsteps//2), samples =
+        post-burn-in chain flattened with lnprob as last column."""
+        self.log.info('Fitting Schechter model to true luminosity function using emcee')
+        pos = self.get_init_walker_values()
+        ndim = pos.shape[1]
+        start = time.time()
+        sampler = EnsembleSampler(self.nwalkers, ndim, getattr(self, self._lnprob_name()), vectorize=True)
+        sampler.run_mcmc(pos, self.nsteps, rstate0=np.random.get_state())
+        elapsed = time.time() - start
+        self.log.info("Total time taken: %0.2f s" % elapsed)
+        self.log.info("Time taken per step per walker: %0.2f ms" % (elapsed / (self.nsteps) * 1000. / self.nwalkers))
+        tau = np.max(sampler.acor)
+        burnin_step = int(tau * 3)
+        if burnin_step > self.nsteps // 2:
+            burnin_step = self.nsteps // 2
+        self.log.info("Mean acceptance fraction: %0.2f" % (np.mean(sampler.acceptance_fraction)))
+        self.log.info("AutoCorrelation Steps: %i, Number of Burn-in Steps: %i" % (np.round(tau), burnin_step))
+        new_chain = np.zeros((self.nwalkers, self.nsteps, ndim + 1))
+        new_chain[:, :, :-1] = sampler.chain
+        self.chain = sampler.chain
+        new_chain[:, :, -1] = sampler.lnprobability
+        self.samples = new_chain[:, burnin_step:, :].reshape((-1, ndim + 1))
+        self.sampler = sampler
+        self.log.info("Shape of self.samples")
+        self.log.info(self.samples.shape)
+        self.log.info("Median lnprob: %.5f; Max lnprob: %.5f" % (np.median(sampler.lnprobability),
+                                                                np.amax(sampler.lnprobability)))
+
+    def _select_samples(self, lnprobcut, keep_lnprob):
+        """Rows within lnprobcut of the maximum, doubling the cut until a quarter survive
+        (lumfuncmcmc.py:548-553)."""
+        nsamples = []
+        while len(nsamples) < len(self.samples) // 4:
+            sel = self.samples[:, -1] > (np.max(self.samples[:, -1], axis=0) - lnprobcut)
+            nsamples = self.samples[sel, :] if keep_lnprob else self.samples[sel, :-1]
+            lnprobcut *= 2.0
+        self.log.info("Shape of nsamples (with a lnprobcut applied)")
+        self.log.info(nsamples.shape)
+        return nsamples
+
+    def add_fitinfo_to_table(self, percentiles, start_value=1, lnprobcut=7.5):
+        """Percentiles of each parameter into the last row of self.table (lumfuncmcmc.py:653-667)."""
+        nsamples = self._select_samples(lnprobcut, keep_lnprob=False)
+        n = len(percentiles)
+        for i, per in enumerate(percentiles):
+            for j, v in enumerate(np.percentile(nsamples, per, axis=0)):
+                self.table[-1][(i + start_value + j * n)] = v
+
+    def _veff_or_skip(self):
+        try:
+            self.VeffLF()
+        except NotImplementedError as e:
+            self.log.warning("skipping the 1/Veff estimate: %s" % e)
+            self.Lavg = self.lfbinorig = self.var = None
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+
+class LumFuncMCMC(_Base):
+    """Single-Schechter fit with free or fixed completeness parameters (lumfuncmcmc.py:72)."""
+
+    def __init__(self, z, flux=None, flux_e=None, Flim=[2.35, 3.12, 2.20, 2.86, 2.85], Flim_lims=[1.0, 6.0],
+                 alpha=3.5, alpha_lims=[1.0, 6.0], line_name="OIII",
+                 line_plot_name=r'[OIII] $\lambda 5007$', lum=None, lum_e=None,
+                 Omega_0=[100.0, 100.0, 100.0, 100.0, 100.0], nbins=50,
+                 nboot=100, sch_al=-1.6, sch_al_lims=[-3.0, 1.0], Lstar=42.5, Lstar_lims=[40.0, 45.0],
+                 phistar=-3.0, phistar_lims=[-8.0, 5.0], Lc=40.0, Lh=46.0, nwalkers=100, nsteps=1000,
+                 fix_sch_al=False, fcmin=0.1, fix_comp=False, min_comp_frac=0.5,
+                 field_names=None, field_ind=None, diff_rand=True, device=0):
+        self._common_init(z, flux, flux_e, lum, lum_e)
+        self.device = device
+        self.fcmin, self.min_comp_frac = fcmin, min_comp_frac
+        self.Flim, self.Flim_lims = Flim, Flim_lims
+        self.fields, self.nfields = field_names, len(self.Flim)
+        self.field_ind = field_ind
+        self.alpha, self.alpha_lims = alpha, alpha_lims
+        self.line_name, self.line_plot_name = line_name, line_plot_name
+        self.Lc, self.Lh = Lc, Lh
+        self.Omega_0 = Omega_0
+        self.nbins, self.nboot = nbins, nboot
+        self.sch_al, self.sch_al_lims = sch_al, sch_al_lims
+        self.Lstar, self.Lstar_lims = Lstar, Lstar_lims
+        self.phistar, self.phistar_lims = phistar, phistar_lims
+        self.nwalkers, self.nsteps = nwalkers, nsteps
+        self.fix_sch_al, self.fix_comp = fix_sch_al, fix_comp
+        self.all_param_names = ['Lstar', 'phistar', 'sch_al', 'Flim', 'alpha']
+        self.diff_rand = diff_rand
+        self._Flim0, self._alpha0 = list(Flim), alpha          # the fixed completeness of this object
+        self.defineFlimOmArr()
+        self.getRoot()
+        self.setDLdVdz()
+        self._fluxes_and_lums(flux, flux_e, lum, lum_e)
+        self._Omegaf = None
+        self.roots_ln = self.rootsf.ev(self.Flim, self.alpha)
+        self.allind = np.arange(len(self.lum))
+        self.size_ln = 201 if self.fix_comp else 101
+        self.setlnsimple(need_integ=bool(self.fix_comp))
+        self.setup_logging()
+
+    def getRoot(self, size=201):
+        self.rootsf = hs.completeness_roots(self.Flim_lims, self.alpha_lims, self.fcmin, self.min_comp_frac, size)
+
+    def _setup_roots(self):
+        return self.rootsf.ev(self.Flim, self.alpha)
+
+    def _variant(self):
+        return "fixcomp" if self.fix_comp else "free"
+
+    def _lnprob_name(self):
+        return 'lnprob_fix_comp' if self.fix_comp else 'lnprob'
+
+    def set_parameters_from_list(self, input_list):
+        """theta -> named attributes (lumfuncmcmc.py:320-337); kept for the post-processing code,
+        the kernels unpack theta themselves."""
+        self.Lstar, self.phistar = input_list[0], input_list[1]
+        k = 2
+        if not self.fix_sch_al:
+            self.sch_al = input_list[2]
+            k = 3
+        if not self.fix_comp:
+            self.Flim, self.alpha = input_list[k:k + self.nfields], input_list[k + self.nfields]
+
+    def lnprob(self, theta):
+        """log posterior, completeness free (lumfuncmcmc.py:395-409).  theta: (ndim,) -> float, or
+        (B, ndim) -> (B,) in one device call."""
+        if self.fix_comp:
+            raise ValueError("this object was built with fix_comp=True: call lnprob_fix_comp")
+        return self._evaluate(theta)
+
+    def lnprob_fix_comp(self, theta):
+        """log posterior, completeness fixed (lumfuncmcmc.py:411-424)."""
+        if not self.fix_comp:
+            raise ValueError("this object was built with fix_comp=False (S=101 grid): call lnprob")
+        return self._evaluate(theta)
+
+    def _theta_lims(self):
+        lims = [self.Lstar_lims, self.phistar_lims]
+        if not self.fix_sch_al:
+            lims.append(self.sch_al_lims)
+        if not self.fix_comp:
+            lims += [self.Flim_lims] * self.nfields + [self.alpha_lims]
+        return np.array(lims, dtype=np.float64)
+
+    def get_param_names(self):
+        names = [r'$\log L_*$', r'$\log \phi_*$']
+        if not self.fix_sch_al:
+            names += [r'$\alpha$']
+        if not self.fix_comp:
+            names += [r'$F_{{\rm 50},%d}$' % (i) for i in range(self.nfields)] + [r'$\alpha_C$']
+        return names
+
+    def get_params(self):
+        vals = [self.Lstar, self.phistar]
+        if not self.fix_sch_al:
+            vals += [self.sch_al]
+        if not self.fix_comp:
+            vals += list(self.Flim) + [self.alpha]
+        self.nfreeparams = len(vals)
+        return vals
+
+    def set_median_fit(self, rndsamples=200, lnprobcut=7.5):
+        """Median model LF over random posterior draws (lumfuncmcmc.py:527-567), without the
+        1/Veff estimator (VeffLF is outside this build's scope: SURVEY.md section 8f row 3)."""
+        nsamples = self._select_samples(lnprobcut, keep_lnprob=True)
+        Flims, alphas = np.zeros((rndsamples, self.nfields)), np.zeros(rndsamples)
+        lf = []
+        for i in np.arange(rndsamples):
+            ind = np.random.randint(0, nsamples.shape[0])
+            self.set_parameters_from_list(nsamples[ind, :])
+            Flims[i], alphas[i] = self.Flim, self.alpha
+            lf.append(TrueLumFunc(self.lum, self.sch_al, self.Lstar, self.phistar))
+        self.medianLF = np.median(np.array(lf), axis=0)
+        self.Flim, self.alpha = list(np.median(Flims, axis=0)), np.median(alphas)
+        self._veff_or_skip()
+
+    def VeffLF(self):
+        raise NotImplementedError("VeffLF (1/Veff estimator with bootstrap errors, lumfuncmcmc.py:515-525) "
+                                  "is a post-fit diagnostic outside the scope of this build")
+
+    def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
+        raise NotImplementedError("triangle_plot needs corner/matplotlib and VeffLF; outside the scope of this build")
+
+
+class LumFuncMCMCz(_Base):
+    """Schechter fit whose log L* and log phi* are quadratics in z through three pivots
+    (lumfuncmcmc_z.py:118); completeness is always fixed in this class."""
+
+    _logger_name = 'lumfuncmcmc_z'
+
+    def __init__(self, z, flux=None, flux_e=None, Flim=[2.35, 3.12, 2.20, 2.86, 2.85],
+                 alpha=3.5, line_name="OIII",
+                 line_plot_name=r'[OIII] $\lambda 5007$', lum=None, lum_e=None,
+                 Omega_0=[100.0, 100.0, 100.0, 100.0, 100.0], nbins=50,
+                 nboot=100, sch_al=-1.6, sch_al_lims=[-3.0, 1.0], Lstar=42.5, Lstar_lims=[41.0, 45.0],
+                 phistar=-3.0, phistar_lims=[-8.0, 5.0], Lc=40.0, Lh=46.0, nwalkers=100, nsteps=1000,
+                 fcmin=0.1, min_comp_frac=0.5, field_names=None,
+                 field_ind=None, z1=1.20, z2=1.53, z3=1.86, fix_sch_al=False, device=0):
+        self._common_init(z, flux, flux_e, lum, lum_e)
+        self.device = device
+        self.z1, self.z2, self.z3 = z1, z2, z3
+        self.fcmin, self.min_comp_frac = fcmin, min_comp_frac
+        self.Flim = Flim
+        self.fields, self.nfields = field_names, len(self.Flim)
+        self.field_ind = field_ind
+        self.alpha = alpha
+        self.line_name, self.line_plot_name = line_name, line_plot_name
+        self.Lc, self.Lh = Lc, Lh
+        self.Omega_0 = Omega_0
+        self.fix_sch_al = fix_sch_al
+        self.nbins, self.nboot = nbins, nboot
+        self.sch_al, self.sch_al_lims = sch_al, sch_al_lims
+        self.Lstar, self.Lstar_lims = Lstar, Lstar_lims
+        self.phistar, self.phistar_lims = phistar, phistar_lims
+        # six draws from the global state, as the reference makes before anything else (:206-207)
+        self.L1, self.L2, self.L3 = np.random.uniform(self.Lstar_lims[0] + 0.5, self.Lstar_lims[-1] - 0.5, 3)
+        self.phi1, self.phi2, self.phi3 = np.random.uniform(self.phistar_lims[0] + 3, self.phistar_lims[-1] - 3, 3)
+        self.nwalkers, self.nsteps = nwalkers, nsteps
+        self._Flim0, self._alpha0 = list(Flim), alpha
+        self.getRoot()
+        self.defineFlimOmArr()
+        self.setDLdVdz()
+        self._fluxes_and_lums(flux, flux_e, lum, lum_e)
+        self._Omegaf = None
+        self.allind = np.arange(len(self.lum))
+        self.size_ln = 201
+        self.setlnsimple(need_integ=True)
+        self.setup_logging()
+
+    def getRoot(self):
+        """Per-field flux at which the completeness equals min_comp_frac (lumfuncmcmc_z.py:292-297);
+        only read when min_comp_frac > 0.001."""
+        self.roots_ln = np.zeros(self.nfields)
+        if self.min_comp_frac > 0.001:
+            from scipy.optimize import fsolve
+            for i in range(self.nfields):
+                self.roots_ln[i] = fsolve(lambda x: hs.fleming(x, 1.0e-17 * self.Flim[i], self.alpha, self.fcmin)
+                                          - self.min_comp_frac, [1.0e-17 * self.Flim[i]])[0]
+
+    def _setup_roots(self):
+        return self.roots_ln
+
+    def defineFlimOmArr(self):
+        _Base.defineFlimOmArr(self)
+        self.roots_arr = np.zeros(self.field_ind[-1])
+        for ii in range(self.nfields):
+            self.roots_arr[self.field_ind[ii]:self.field_ind[ii + 1]] = self.roots_ln[ii]
+
+    def _variant(self):
+        return "zevol"
+
+    def set_parameters_from_list(self, input_list):
+        self.L1, self.L2, self.L3 = input_list[0], input_list[1], input_list[2]
+        self.phi1, self.phi2, self.phi3 = input_list[3], input_list[4], input_list[5]
+        if not self.fix_sch_al:
+            self.sch_al = input_list[6]
+
+    def lnprob(self, theta):
+        """log posterior (lumfuncmcmc_z.py:378-392).  theta: (ndim,) -> float or (B, ndim) -> (B,)."""
+        return self._evaluate(theta)
+
+    def _theta_lims(self):
+        lims = [self.Lstar_lims] * 3 + [self.phistar_lims] * 3
+        if not self.fix_sch_al:
+            lims.append(self.sch_al_lims)
+        return np.array(lims, dtype=np.float64)
+
+    def get_init_walker_values(self, num=None):
+        lims = self._theta_lims()
+        if num is None:
+            num = self.nwalkers
+        return np.random.rand(num, len(lims)) * (lims[:, 1] - lims[:, 0]) + lims[:, 0]
+
+    def get_param_names(self):
+        names = [r'$\log {\rm{L}}1_*$', r'$\log {\rm{L}}2_*$', r'$\log {\rm{L}}3_*$',
+                 r'$\log \phi1_*$', r'$\log \phi2_*$', r'$\log \phi3_*$']
+        if not self.fix_sch_al:
+            names += [r'$\alpha$']
+        return names
+
+    def get_params(self):
+        vals = [self.L1, self.L2, self.L3, self.phi1, self.phi2, self.phi3]
+        if not self.fix_sch_al:
+            vals += [self.sch_al]
+        self.nfreeparams = len(vals)
+        return vals
+
+    def set_median_fit(self, lnprobcut=7.5, zlen=100, Llen=100):
+        """Median-parameter LF surface on a (z, L) mesh (lumfuncmcmc_z.py:480-513), without VeffLF."""
+        nsamples = self._select_samples(lnprobcut, keep_lnprob=False)
+        self.Lout = np.linspace(min(self.lum) - 0.2, max(self.lum) + 0.2, Llen)
+        self.zout = np.linspace(self.zmin, self.zmax, zlen)
+        self.medianLF = np.zeros((zlen, Llen))
+        self.set_parameters_from_list(np.percentile(nsamples, 50.0, axis=0))
+        for i in np.arange(zlen):
+            self.medianLF[i] = schechter_z(self.Lout, self.zout[i], self.sch_al, self.L1, self.L2, self.L3,
+                                           self.phi1, self.phi2, self.phi3, self.z1, self.z2, self.z3)
+        self._veff_or_skip()
+
+    def VeffLF(self):
+        raise NotImplementedError("VeffLF (lumfuncmcmc_z.py:470-478) is a post-fit diagnostic outside "
+                                  "the scope of this build")
+
+    def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
+        raise NotImplementedError("triangle_plot needs corner/matplotlib and VeffLF; outside the scope of this build")

@@ -92,7 +92,7 @@ def compare_rows(got, ref, inp, thetas, rtol, what="lnprob"):
     """-inf pattern identical; finite rows within rtol, except rows in the subnormal band, where
     the reference's own value is quantised: there both must be below -700 and within 1e-3."""
     got, ref = np.asarray(got), np.asarray(ref)
-    assert not np.isnan(got).any(), "%s: NaN from the kernel" % what
+    assert not np.isnan(got[~np.isnan(ref)]).any(), "%s: NaN from the kernel" % what
     worst = 0.0
     for i in range(len(ref)):
         if np.isnan(ref[i]):
