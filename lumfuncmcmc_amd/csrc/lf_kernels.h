@@ -1,30 +1,39 @@
 // lf_kernels.h - HIP kernels of the per-step log-posterior (gfx950, fp64 VALU).
 //
-// Work decomposition (both pieces): a workgroup owns (one chunk of items) x (one tile of TW
-// walkers).  Items - catalogue sources for piece A, integration-grid nodes for piece B - sit on
-// the 64 lanes of each wave and are loaded once, coalesced, into registers; the walker loop is
-// unrolled and every walker-only quantity is wave-uniform, so the compiler keeps it in SGPRs
-// (scalar loads, no LDS traffic, no VGPRs).  Each lane keeps TW running sums; a wave
-// __shfl_down tree, then a 4-wave LDS step, gives one partial per (chunk, walker), written to
-// HBM in a fixed slot; lf_finalize adds the partials in a fixed order, so results are bitwise
-// reproducible for a given launch geometry.
+// Work decomposition (both pieces): a workgroup of 256 threads owns (one chunk of items) x (one
+// tile of up to TW walkers).  Items - catalogue sources for piece A, integration-grid nodes for
+// piece B - are loaded ONCE, coalesced, into registers (ST per lane) and stay there while the
+// workgroup walks over its walkers.  Everything walker-only is wave-uniform, so it lives in SGPRs
+// (scalar loads from the walker record; no LDS traffic, no VGPRs).  Per walker each lane adds its
+// ST terms and parks the sum in LDS; after the walker loop the four waves reduce the TW x 256
+// sums with 64-lane __shfl_down trees and write one partial per (chunk, walker) to a fixed slot.
+// lf_finalize adds the partials in a fixed order: results are bitwise reproducible for a given
+// launch geometry.
 //
 // The arithmetic is that of SURVEY.md App. A (reference: lumfuncmcmc.py:44, :69-70, :370-377,
 // :388-392; lumfuncmcmc_z.py:40-42, :63-67, :371-375; VmaxLumFunc.py:118-127, :141, :164-167),
 // evaluated in log space with everything source-only or walker-only hoisted:
 //     10^(lum_i - L*)   = P_i * Q_w        P_i = 10^(lum_i - 42),  Q_w = 10^(42 - L*_w)
 //     f_i / f_tau(w,f)  = U_i * V_wf       U_i = 10^(logf_i + 17), V_wf = 1 / (Flim_f 10^b_w)
-// The reference's -inf (log of a product that underflowed to 0) is reproduced by poisoning the
-// running sum with -inf whenever a factor or the product would round to zero in binary64.
+//
+// Underflow convention: the reference takes log(product) in linear space and
+// returns -inf as soon as one source's product rounds to 0.  lf_prepare classifies every
+// (walker, field) from per-field extremes of the catalogue:
+//     NEGINF  the brightest source already underflows exp(-10^(lum-L*))   -> lnprob = -inf, exactly
+//     FAST    a lower bound of every factor is far above the underflow threshold (the normal case)
+//             -> branch-free terms with the tuned math of lf_math.h, no per-term checks
+//     SLOW    anything else -> per-term checks with the device-library math, -inf poisoning
+// The mode is uniform per workgroup (tile x field), so the choice costs one scalar branch.
 #pragma once
 #include "lf_math.h"
 
 namespace lf {
 
-constexpr int TW = 8;        // walkers per workgroup tile
 constexpr int BLOCK = 256;   // 4 waves
 constexpr int REC = 24;      // doubles per walker record
 constexpr int MAXF = 8;
+enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2 };
+enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2 };
 
 // walker record, FREE / FIXCOMP
 enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4, R_LF = 8, R_V = 16 };
@@ -40,6 +49,14 @@ struct KConst {
     double pivots[3];
     double sch_al0, alpha0;
     double flim0[MAXF];
+    // per-field extremes of the catalogue, for the mode classification
+    int nsrc[MAXF];
+    double pmax[MAXF];        // max 10^(lum-42)            (FREE, FIXCOMP)
+    double lum_min[MAXF], lum_max[MAXF];
+    double a_min[MAXF];       // FREE: min logf             FIXCOMP/ZEVOL: min ln(Om_arr)
+    double u_min[MAXF];       // FREE: 10^(min logf + 17)
+    double u_max[MAXF];       // FREE: 10^(max logf + 17)
+    double z_lo[MAXF], z_hi[MAXF];   // ZEVOL
 };
 
 // getQuadCoef, lumfuncmcmc_z.py:40-42, with the reference's operation order and no FMA contraction
@@ -52,40 +69,73 @@ __device__ inline void quad_coef(double y1, double y2, double y3, double z1, dou
     c = y1 - a * z1s - b * z1;
 }
 
+// a z^2 + b z + c with the reference's roundings (lumfuncmcmc_z.py:65-66): with close pivots the
+// three terms cancel by two or three digits, so an FMA-contracted form drifts by ~1e-13 relative.
+__device__ __forceinline__ double quad_nofma(double a, double b, double c, double z, double z2) {
+    return __dadd_rn(__dadd_rn(__dmul_rn(a, z2), __dmul_rn(b, z)), c);
+}
+
+__device__ inline void quad_range(double a, double b, double c, double lo, double hi, double& mn, double& mx) {
+    const double v0 = quad_nofma(a, b, c, lo, lo * lo), v1 = quad_nofma(a, b, c, hi, hi * hi);
+    mn = fmin(v0, v1);
+    mx = fmax(v0, v1);
+    if (a != 0.0) {
+        const double zv = -b / (2.0 * a);
+        if (zv > lo && zv < hi) {
+            const double vv = quad_nofma(a, b, c, zv, zv * zv);
+            mn = fmin(mn, vv);
+            mx = fmax(mx, vv);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
-// prepare: theta rows -> walker records + prior flag.  One thread per (padded) walker.
+// prepare: theta rows -> walker records, prior flag, per-(walker, field) mode.  One thread per walker.
 // set_parameters_from_list + lnprior: lumfuncmcmc.py:327-358, lumfuncmcmc_z.py:339-362.
 // ----------------------------------------------------------------------------------------------
-__global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B, int Bpad,
-                           double* __restrict__ wrec, int* __restrict__ prior_ok) {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= Bpad) return;
-    int ws = w < B ? w : B - 1;                 // padding walkers replay the last real one
-    const double* th = theta + (size_t)ws * kc.ndim;
+__global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
+                           double* __restrict__ wrec, int* __restrict__ wstat, int* __restrict__ wmode) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= B) return;
+    const double* th = theta + (size_t)w * kc.ndim;
     double* r = wrec + (size_t)w * REC;
     for (int i = 0; i < REC; ++i) r[i] = 0.0;
-    bool ok = true;
+    int* mode = wmode + (size_t)w * MAXF;
+    const double SAFE = -700.0;
+    bool ok = true, neginf = false;
     if (kc.variant == LF_ZEVOL) {
-        double L1 = th[0], L2 = th[1], L3 = th[2], p1 = th[3], p2 = th[4], p3 = th[5];
-        double al = kc.fix_sch_al ? kc.sch_al0 : th[6];
+        const double L1 = th[0], L2 = th[1], L3 = th[2], p1 = th[3], p2 = th[4], p3 = th[5];
+        const double al = kc.fix_sch_al ? kc.sch_al0 : th[6];
         if (!kc.fix_sch_al) ok = ok && (al >= kc.lims[LF_LIM_SCH_AL][0]) && (al <= kc.lims[LF_LIM_SCH_AL][1]);
         const double Ls[3] = {L1, L2, L3}, ps[3] = {p1, p2, p3};
         for (int i = 0; i < 3; ++i) {           // strict for L and phi (lumfuncmcmc_z.py:355-358)
             ok = ok && (Ls[i] > kc.lims[LF_LIM_LSTAR][0]) && (Ls[i] < kc.lims[LF_LIM_LSTAR][1]);
             ok = ok && (ps[i] > kc.lims[LF_LIM_PHISTAR][0]) && (ps[i] < kc.lims[LF_LIM_PHISTAR][1]);
         }
-        double z1 = kc.pivots[0], z2 = kc.pivots[1], z3 = kc.pivots[2];
-        // getQuadCoef, lumfuncmcmc_z.py:40-42
         double aL, bL, cL, aP, bP, cP;
-        quad_coef(L1, L2, L3, z1, z2, z3, aL, bL, cL);
-        quad_coef(p1, p2, p3, z1, z2, z3, aP, bP, cP);
+        quad_coef(L1, L2, L3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aL, bL, cL);
+        quad_coef(p1, p2, p3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aP, bP, cP);
+        const double c1 = LF_LN10 * (al + 1.0);
         r[Z_AL] = aL; r[Z_BL] = bL; r[Z_CL] = cL;
         r[Z_AP] = aP; r[Z_BP] = bP; r[Z_CP] = cP;
-        r[Z_C1] = LF_LN10 * (al + 1.0);
+        r[Z_C1] = c1;
+        for (int f = 0; f < kc.nf; ++f) {
+            int m = MODE_FAST;
+            if (kc.nsrc[f] > 0) {
+                double lsmn, lsmx, phmn, phmx;
+                quad_range(aL, bL, cL, kc.z_lo[f], kc.z_hi[f], lsmn, lsmx);
+                quad_range(aP, bP, cP, kc.z_lo[f], kc.z_hi[f], phmn, phmx);
+                const double tmax = kc.lum_max[f] - lsmn, tmin = kc.lum_min[f] - lsmx;
+                const double vb = pow(10.0, tmax);
+                const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
+                m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
+            }
+            mode[f] = m;
+        }
     } else {
-        double Lstar = th[0], phistar = th[1];
+        const double Lstar = th[0], phistar = th[1];
         int k = 2;
-        double al = kc.fix_sch_al ? kc.sch_al0 : th[k++];
+        const double al = kc.fix_sch_al ? kc.sch_al0 : th[k++];
         double alphaC = kc.alpha0;
         double Flim[MAXF];
         for (int f = 0; f < kc.nf; ++f) Flim[f] = kc.flim0[f];
@@ -100,61 +150,119 @@ __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B, i
         for (int f = 0; f < kc.nf; ++f)
             ok = ok && (Flim[f] >= kc.lims[LF_LIM_FLIM][0]) && (Flim[f] <= kc.lims[LF_LIM_FLIM][1]);
         ok = ok && (alphaC >= kc.lims[LF_LIM_ALPHA][0]) && (alphaC <= kc.lims[LF_LIM_ALPHA][1]);
+        const double c0 = LF_LNLN10 + LF_LN10 * phistar, c1 = LF_LN10 * (al + 1.0);
+        const double Q = pow(10.0, LF_LREF - Lstar);
         r[R_LSTAR] = Lstar;
-        r[R_C0] = LF_LNLN10 + LF_LN10 * phistar;
-        r[R_C1] = LF_LN10 * (al + 1.0);
-        r[R_Q] = pow(10.0, LF_LREF - Lstar);
+        r[R_C0] = c0;
+        r[R_C1] = c1;
+        r[R_Q] = Q;
+        double tenb = 1.0;
         if (kc.variant == LF_FREE) {
             r[R_ALPHAC] = alphaC;
-            double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
-            double tenb = pow(10.0, b);
-            for (int f = 0; f < kc.nf; ++f) {
-                r[R_LF + f] = log10(1.0e-17 * Flim[f]);
-                r[R_V + f] = 1.0 / (Flim[f] * tenb);
+            const double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
+            tenb = pow(10.0, b);
+        }
+        for (int f = 0; f < kc.nf; ++f) {
+            double lF = 0.0, V = 0.0;
+            if (kc.variant == LF_FREE) {
+                lF = log10(1.0e-17 * Flim[f]);
+                V = 1.0 / (Flim[f] * tenb);
+                r[R_LF + f] = lF;
+                r[R_V + f] = V;
             }
+            int m = MODE_FAST;
+            if (kc.nsrc[f] > 0) {
+                const double vmax = kc.pmax[f] * Q;       // the very product the kernels form for that source
+                const double tlo = kc.lum_min[f] - Lstar, thi = kc.lum_max[f] - Lstar;
+                const double lbT = c0 + fmin(c1 * tlo, c1 * thi) - vmax;
+                if (vmax > LF_UNDERFLOW) {
+                    m = MODE_NEGINF;
+                } else if (kc.variant == LF_FREE) {
+                    const double num = alphaC * (kc.a_min[f] - lF);
+                    const double lnfc = log(0.5 * (1.0 + num * rsqrt(fma(num, num, 1.0))));
+                    const double lnOm = kc.lnom0_src[f] + lnfc / (1.0 - exp(-kc.u_min[f] * V));
+                    // fexp_t takes |x| < 2^24 unclamped: screen the largest f / f_tau of the field as well
+                    m = (lbT > SAFE && lnOm > SAFE && lbT + lnOm > SAFE && kc.u_max[f] * V < 1.0e6) ? MODE_FAST : MODE_SLOW;
+                } else {
+                    m = (lbT > SAFE && lbT + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
+                }
+            }
+            if (m == MODE_NEGINF) neginf = true;
+            mode[f] = m;
         }
     }
-    prior_ok[w] = ok ? 1 : 0;
+    wstat[w] = (ok ? STAT_PRIOR_OK : 0) | (neginf ? STAT_NEGINF : 0);
 }
 
 // ----------------------------------------------------------------------------------------------
-// shared pieces
+// per-term arithmetic
 // ----------------------------------------------------------------------------------------------
-// a z^2 + b z + c with the reference's roundings (lumfuncmcmc_z.py:65-66): with close pivots the
-// three terms cancel by two or three digits, so an FMA-contracted form drifts by ~1e-13 relative.
-__device__ __forceinline__ double quad_nofma(double a, double b, double c, double z, double z2) {
-    return __dadd_rn(__dadd_rn(__dmul_rn(a, z2), __dmul_rn(b, z)), c);
-}
-
 // ln of the Fleming completeness fc = 1/2 (1 + num / sqrt(1 + num^2)), VmaxLumFunc.py:118-120
-__device__ __forceinline__ double ln_fc(double num) {
-    double s = fma(num, num, 1.0);
-    double q = num * drsqrt(s);
-    return dlog(0.5 * (1.0 + q));
+__device__ __forceinline__ double ln_fc_careful(double num) {
+    const double s = fma(num, num, 1.0);
+    return dlog(0.5 * (1.0 + num * drsqrt(s)));
+}
+__device__ __forceinline__ double ln_fc_fast(double num, const MathTables* __restrict__ tab) {
+    const double s = fma(num, num, 1.0);
+    return flog_half(fma(num, frsqrt(s), 1.0), tab);
 }
 
-// block reduction of TW per-lane sums -> out[(tile*TW + w) * stride + chunk]
-__device__ __forceinline__ void block_reduce_store(double (&acc)[TW], double* __restrict__ out,
-                                                   size_t stride, int tile, int chunk) {
-    __shared__ double red[BLOCK / 64][TW];
+struct WFree {   // wave-uniform walker constants of one (walker, field)
+    double Lstar, c0f, c1, Q, alphaC, lF, V, lnom0;
+};
+
+__device__ __forceinline__ double term_free_fast(const WFree& w, double lum, double logf, double P, double U,
+                                                 const MathTables* __restrict__ tab) {
+    const double lnT = fma(w.c1, lum - w.Lstar, w.c0f) - P * w.Q;          // ln TrueLumFunc + ln Omega_0
+    const double lnfc = ln_fc_fast(w.alphaC * (logf - w.lF), tab);
+    const double d = 1.0 - fexp_t(-(U * w.V), tab);                        // expdecay, VmaxLumFunc.py:141
+    return fma(lnfc, frcp(d), lnT);
+}
+
+__device__ __forceinline__ double term_free_careful(const WFree& w, double lum, double logf, double P, double U) {
+    const double NEG_INF = -__builtin_huge_val();
+    const double v = P * w.Q;
+    const double lnT = fma(w.c1, lum - w.Lstar, w.c0f) - v;
+    const double lnfc = ln_fc_careful(w.alphaC * (logf - w.lF));
+    const double d = 1.0 - dexp(-(U * w.V));
+    const double lnOm = w.lnom0 + ddiv(lnfc, d);
+    const double term = (lnT - w.lnom0) + lnOm;
+    const bool bad = (v > LF_UNDERFLOW) | (lnT - w.lnom0 < -LF_UNDERFLOW) | (lnOm < -LF_UNDERFLOW) |
+                     (term < -LF_UNDERFLOW) | (term != term);
+    return bad ? NEG_INF : term;
+}
+
+struct WZ {
+    double aL, bL, cL, aP, bP, cP, c1;
+};
+
+template <bool FAST>
+__device__ __forceinline__ double lnT_zevol(const WZ& w, double lum, double z, double z2, double& v,
+                                            const MathTables* __restrict__ tab) {
+    const double Ls = quad_nofma(w.aL, w.bL, w.cL, z, z2);        // lumfuncmcmc_z.py:66
+    const double ph = quad_nofma(w.aP, w.bP, w.cP, z, z2);        // :65
+    const double t = lum - Ls;
+    v = FAST ? fexp_c(LF_LN10 * t, tab) : dexp(LF_LN10 * t);
+    return fma(w.c1, t, fma(LF_LN10, ph, LF_LNLN10)) - v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// block reduction: red[nw][256] (LDS) -> out[(w0 + w) * stride + chunk]
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_store(const double* __restrict__ red, int nw, double* __restrict__ out,
+                                             size_t stride, int w0, int chunk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int w = 0; w < TW; ++w) {
-        double s = wave_sum(acc[w]);
-        if (lane == 0) red[wave][w] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < TW) {
-        double s = red[0][threadIdx.x];
-#pragma unroll
-        for (int k = 1; k < BLOCK / 64; ++k) s += red[k][threadIdx.x];
-        out[(size_t)(tile * TW + threadIdx.x) * stride + chunk] = s;
+    for (int w = wave; w < nw; w += BLOCK / 64) {
+        const double* row = red + w * BLOCK;
+        double s = (row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]);
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)(w0 + w) * stride + chunk] = s;
     }
 }
 
 // ----------------------------------------------------------------------------------------------
-// piece A: per-source log-term sum.  grid = (chunks, walker tiles)
-// lumfuncmcmc.py:370 (FREE), :388 (FIXCOMP), lumfuncmcmc_z.py:371 (ZEVOL)
+// piece A: per-source log-term sum.  grid = (chunks, walker tiles); chunk = up to 256*ST sources of
+// ONE field.  lumfuncmcmc.py:370 (FREE), :388 (FIXCOMP), lumfuncmcmc_z.py:371 (ZEVOL)
 // ----------------------------------------------------------------------------------------------
 struct SrcArrays {
     const double* lum;    // [N]
@@ -166,73 +274,103 @@ struct SrcArrays {
     const int* chunk_field;
 };
 
-template <int VARIANT>
-__global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa,
-                                                   const double* __restrict__ wrec,
+template <int VARIANT, int ST, int TW>
+__global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, const double* __restrict__ wrec,
+                                                   const int* __restrict__ wmode, int B,
                                                    double* __restrict__ partial, int pstride) {
-    const int c = blockIdx.x, tile = blockIdx.y;
+    __shared__ MathTables tab;
+    __shared__ double red[TW * BLOCK];
+    const int c = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
     const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
-    const double* __restrict__ wr = wrec + (size_t)tile * TW * REC;
-    const double NEG_INF = -__builtin_huge_val();
-    double acc[TW];
-#pragma unroll
-    for (int w = 0; w < TW; ++w) acc[w] = 0.0;
+    const int w0 = tile * TW;
+    const int nw = min(TW, B - w0);
+    load_tables(&tab);
 
-    for (int i = threadIdx.x; i < n; i += BLOCK) {
-        const size_t g = (size_t)s0 + i;
-        const double lum = sa.lum[g];
-        if (VARIANT == LF_FREE) {
-            const double logf = sa.a1[g], P = sa.P[g], U = sa.U[g];
-            const double lnom0 = kc.lnom0_src[fld];
+    // items -> registers (lanes past the end replay the chunk's first source with weight 0)
+    double lum[ST], a1[ST], pp[ST], uu[ST], wgt[ST];
 #pragma unroll
-            for (int w = 0; w < TW; ++w) {
-                const double* r = wr + w * REC;
-                const double t = lum - r[R_LSTAR];
-                const double v = P * r[R_Q];                       // 10^(lum - L*)
-                const double lnT = fma(r[R_C1], t, r[R_C0]) - v;   // ln TrueLumFunc
-                const double x = logf - r[R_LF + fld];             // log10(f / Flim)
-                const double lnfc = ln_fc(r[R_ALPHAC] * x);
-                const double u = U * r[R_V + fld];                 // f / f_tau
-                const double d = 1.0 - dexp(-u);                   // expdecay, VmaxLumFunc.py:141
-                const double lnOm = lnom0 + ddiv(lnfc, d);         // ln Omega
-                const double term = lnT + lnOm;
-                const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (lnOm < -LF_UNDERFLOW) |
-                                 (term < -LF_UNDERFLOW);
-                acc[w] += bad ? NEG_INF : term;
-            }
-        } else if (VARIANT == LF_FIXCOMP) {
-            const double lnOm = sa.a1[g], P = sa.P[g];
+    for (int k = 0; k < ST; ++k) {
+        const int i = k * BLOCK + tid;
+        const size_t g = (size_t)s0 + (i < n ? i : 0);
+        wgt[k] = i < n ? 1.0 : 0.0;
+        lum[k] = sa.lum[g];
+        a1[k] = sa.a1[g];
+        pp[k] = sa.P[g];
+        uu[k] = VARIANT == LF_FIXCOMP ? 0.0 : sa.U[g];
+    }
+    int mode = MODE_FAST;
+    for (int w = 0; w < nw; ++w) mode = max(mode, wmode[(size_t)(w0 + w) * MAXF + fld]);
+    mode = __builtin_amdgcn_readfirstlane(mode);
+    __syncthreads();
+
+    const double NEG_INF = -__builtin_huge_val();
+    if (mode == MODE_FAST) {
+#pragma unroll 1
+        for (int w = 0; w < nw; ++w) {
+            const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+            double acc = 0.0;
+            if (VARIANT == LF_FREE) {
+                const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
+                               r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
 #pragma unroll
-            for (int w = 0; w < TW; ++w) {
-                const double* r = wr + w * REC;
-                const double t = lum - r[R_LSTAR];
-                const double v = P * r[R_Q];
-                const double lnT = fma(r[R_C1], t, r[R_C0]) - v;
-                const double term = lnT + lnOm;
-                const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW);
-                acc[w] += bad ? NEG_INF : term;
-            }
-        } else {
-            const double z = sa.a1[g], lnOm = sa.P[g], z2 = sa.U[g];
+                for (int k = 0; k < ST; ++k)
+                    acc = fma(term_free_fast(wf, lum[k], a1[k], pp[k], uu[k], &tab), wgt[k], acc);
+            } else if (VARIANT == LF_FIXCOMP) {
+                const double Lstar = r[R_LSTAR], c0 = r[R_C0], c1 = r[R_C1], Q = r[R_Q];
 #pragma unroll
-            for (int w = 0; w < TW; ++w) {
-                const double* r = wr + w * REC;
-                const double Ls = quad_nofma(r[Z_AL], r[Z_BL], r[Z_CL], z, z2);   // lumfuncmcmc_z.py:66
-                const double ph = quad_nofma(r[Z_AP], r[Z_BP], r[Z_CP], z, z2);   // :65
-                const double t = lum - Ls;
-                const double v = dexp(LF_LN10 * t);
-                const double lnT = fma(r[Z_C1], t, fma(LF_LN10, ph, LF_LNLN10)) - v;
-                const double term = lnT + lnOm;
-                const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW);
-                acc[w] += bad ? NEG_INF : term;
+                for (int k = 0; k < ST; ++k) {
+                    const double lnT = fma(c1, lum[k] - Lstar, c0) - pp[k] * Q;
+                    acc = fma(lnT + a1[k], wgt[k], acc);
+                }
+            } else {
+                const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
+#pragma unroll
+                for (int k = 0; k < ST; ++k) {
+                    double v;
+                    const double lnT = lnT_zevol<true>(wz, lum[k], a1[k], uu[k], v, &tab);
+                    acc = fma(lnT + pp[k], wgt[k], acc);
+                }
             }
+            red[w * BLOCK + tid] = acc;
+        }
+    } else {
+        // careful path: device-library math, per-term underflow checks, -inf poisoning
+#pragma unroll 1
+        for (int w = 0; w < nw; ++w) {
+            const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < ST; ++k) {   // static indices: the item registers must not go to scratch
+                double term;
+                if (VARIANT == LF_FREE) {
+                    const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
+                                   r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
+                    term = term_free_careful(wf, lum[k], a1[k], pp[k], uu[k]);
+                } else if (VARIANT == LF_FIXCOMP) {
+                    const double v = pp[k] * r[R_Q];
+                    const double lnT = fma(r[R_C1], lum[k] - r[R_LSTAR], r[R_C0]) - v;
+                    term = lnT + a1[k];
+                    const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
+                    term = bad ? NEG_INF : term;
+                } else {
+                    const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
+                    double v;
+                    const double lnT = lnT_zevol<false>(wz, lum[k], a1[k], uu[k], v, &tab);
+                    term = lnT + pp[k];
+                    const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
+                    term = bad ? NEG_INF : term;
+                }
+                acc += wgt[k] != 0.0 ? term : 0.0;
+            }
+            red[w * BLOCK + tid] = acc;
         }
     }
-    block_reduce_store(acc, partial, (size_t)pstride, tile, c);
+    __syncthreads();
+    reduce_store(red, nw, partial, (size_t)pstride, w0, c);
 }
 
 // ----------------------------------------------------------------------------------------------
-// piece B: expected-count integral on the S x S grid.  grid = (node chunks, walker tiles)
+// piece B: expected-count integral on the S x S grid.  grid = (node chunks of 256, walker tiles)
 // trapz(trapz(I, logL, axis=0), zarr) = sum_jk W_jk I_jk with W from the actual grid spacings.
 // lumfuncmcmc.py:373-377 (FREE), :389-392 (FIXCOMP), lumfuncmcmc_z.py:373-375 (ZEVOL)
 // ----------------------------------------------------------------------------------------------
@@ -245,54 +383,46 @@ struct NodeArrays {
     int nnodes;
 };
 
-template <int VARIANT>
-__global__ __launch_bounds__(BLOCK) void lf_gridsum(KConst kc, NodeArrays na,
-                                                    const double* __restrict__ wrec,
-                                                    double* __restrict__ partial, int pstride) {
-    const int c = blockIdx.x, tile = blockIdx.y;
-    const double* __restrict__ wr = wrec + (size_t)tile * TW * REC;
-    double acc[TW];
-#pragma unroll
-    for (int w = 0; w < TW; ++w) acc[w] = 0.0;
-    const int g = c * BLOCK + threadIdx.x;
-    if (g < na.nnodes) {
-        const double G = na.G[g], PG = na.PG[g], W = na.W[g];
+template <int VARIANT, int TW>
+__global__ __launch_bounds__(BLOCK) void lf_gridsum(KConst kc, NodeArrays na, const double* __restrict__ wrec,
+                                                    int B, double* __restrict__ partial, int pstride) {
+    __shared__ MathTables tab;
+    __shared__ double red[TW * BLOCK];
+    const int c = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
+    const int w0 = tile * TW;
+    const int nw = min(TW, B - w0);
+    load_tables(&tab);
+    const int gi = c * BLOCK + tid;
+    const bool valid = gi < na.nnodes;
+    const int g = valid ? gi : 0;
+    const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0;
+    const double a3 = na.a3[g], a4 = na.a4[g];
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < nw; ++w) {
+        const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+        double val;
         if (VARIANT == LF_FREE) {
-            const double logf = na.a3[g], UG = na.a4[g];
-#pragma unroll
-            for (int w = 0; w < TW; ++w) {
-                const double* r = wr + w * REC;
-                const double t = G - r[R_LSTAR];
-                const double T = dexp(fma(r[R_C1], t, r[R_C0]) - PG * r[R_Q]);
-                double s = 0.0;
-                for (int f = 0; f < kc.nf; ++f) {
-                    const double lnfc = ln_fc(r[R_ALPHAC] * (logf - r[R_LF + f]));
-                    const double d = 1.0 - dexp(-UG * r[R_V + f]);
-                    s = fma(kc.om0_grid[f], dexp(ddiv(lnfc, d)), s);     // fc ** (1 / fc_decay)
-                }
-                acc[w] = fma(W * T, s, acc[w]);
+            const double T = fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
+            const double alphaC = r[R_ALPHAC];
+            double s = 0.0;
+            for (int f = 0; f < kc.nf; ++f) {
+                const double lnfc = ln_fc_fast(alphaC * (a3 - r[R_LF + f]), &tab);
+                const double d = fmax(1.0 - fexp_c(-(a4 * r[R_V + f]), &tab), 1e-300);
+                s = fma(kc.om0_grid[f], fexp_c(lnfc * frcp(d), &tab), s);          // fc ** (1 / fc_decay)
             }
+            val = W * T * s;
         } else if (VARIANT == LF_FIXCOMP) {
-#pragma unroll
-            for (int w = 0; w < TW; ++w) {
-                const double* r = wr + w * REC;
-                const double t = G - r[R_LSTAR];
-                acc[w] = fma(W, dexp(fma(r[R_C1], t, r[R_C0]) - PG * r[R_Q]), acc[w]);
-            }
+            val = W * fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
         } else {
-            const double z = na.a3[g], z2 = na.a4[g];
-#pragma unroll
-            for (int w = 0; w < TW; ++w) {
-                const double* r = wr + w * REC;
-                const double Ls = quad_nofma(r[Z_AL], r[Z_BL], r[Z_CL], z, z2);
-                const double ph = quad_nofma(r[Z_AP], r[Z_BP], r[Z_CP], z, z2);
-                const double t = G - Ls;
-                const double lnT = fma(r[Z_C1], t, fma(LF_LN10, ph, LF_LNLN10)) - dexp(LF_LN10 * t);
-                acc[w] = fma(W, dexp(lnT), acc[w]);
-            }
+            const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
+            double v;
+            val = W * fexp_c(lnT_zevol<true>(wz, G, a3, a4, v, &tab), &tab);
         }
+        red[w * BLOCK + tid] = val;
     }
-    block_reduce_store(acc, partial, (size_t)pstride, tile, c);
+    __syncthreads();
+    reduce_store(red, nw, partial, (size_t)pstride, w0, c);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -301,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void lf_gridsum(KConst kc, NodeArrays na,
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,
                                                   const double* __restrict__ partB, int nchB, int strideB,
-                                                  const int* __restrict__ prior_ok, int B,
+                                                  const int* __restrict__ wstat, int B,
                                                   double* __restrict__ out, double* __restrict__ outA,
                                                   double* __restrict__ outB) {
     const int w = blockIdx.x;
@@ -315,7 +445,9 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
     a = wave_sum(a);
     b = wave_sum(b);
     if (lane == 0) {
-        const bool ok = prior_ok[w] != 0;
+        const int st = wstat[w];
+        const bool ok = (st & STAT_PRIOR_OK) != 0;
+        if ((st & STAT_NEGINF) || a != a) a = -__builtin_huge_val();
         double r = a - b;
         if (!ok || r != r) r = -__builtin_huge_val();
         if (out) out[w] = r;

@@ -1,15 +1,23 @@
 // lf_math.h - fp64 device math for the lnprob kernels (gfx950).
 //
-// Everything on the path is fp64 VALU work: there is no contraction, so no MFMA.
-// Round-1 baseline: the ROCm device-library (ocml) routines, which are <= 1 ulp.
-// The wrappers exist so that a tuned range-reduction + FMA-polynomial version can be
-// swapped in kernel by kernel and A/B-checked against these.
+// Everything on the path is fp64 VALU work: there is no contraction, so no MFMA.  The terms are
+// dominated by exp / log / rsqrt / reciprocal, so the kernels carry their own versions, sized
+// for this path (known argument ranges, ~1 ulp, no special-case branches):
+//   fexp_t     table-driven: 64-entry 2^(j/64) table in LDS, magic-number rounding (no cvt),
+//              degree-5 polynomial on |r| <= ln2/128, ldexp
+//   flog_half  table-driven: 128 x {1/c, log c} in LDS, degree-6 log1p on |r| < 2^-8
+//   frsqrt     v_rsq_f64 seed (2^-24 measured on gfx950) + one cubic step
+//   frcp       v_rcp_f64 seed (2^-24) + one cubic Newton step
+// The "careful" path (rare walkers that may underflow, see lf_kernels.h) uses the ROCm device
+// library (ocml) versions; tests compare both against the oracle.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "lf_tables.h"
+
 #define LF_LN10 2.302585092994045684
 #define LF_LNLN10 0.834032445247955959       // ln(ln 10)
-#define LF_LOG10E 0.434294481903251828
+#define LF_LN2 0.693147180559945309
 // exp(-v) rounds to +0 in binary64 for v > ln(2^1075); log of a product below 2^-1075 is -inf.
 #define LF_UNDERFLOW 745.13321910194122
 #define LF_LREF 42.0        // P_i = 10^(lum_i - LF_LREF),  Q_w = 10^(LF_LREF - L*_w)
@@ -19,10 +27,78 @@
 
 namespace lf {
 
+// ---- careful versions (device library)
 __device__ __forceinline__ double dexp(double x) { return exp(x); }
 __device__ __forceinline__ double dlog(double x) { return log(x); }
 __device__ __forceinline__ double drsqrt(double x) { return rsqrt(x); }
 __device__ __forceinline__ double ddiv(double a, double b) { return a / b; }
+
+// ---- fast versions
+// LDS image of the tables of lf_tables.h
+struct MathTables {
+    double2 logt[128];   // {1/c_j, log c_j}
+    double expt[64];     // 2^(j/64)
+};
+
+// e^x, table-driven: 64 x / ln2 = 64 n + j + (64 / ln2) r, |r| <= ln2/128, e^x = 2^n 2^(j/64) e^r.
+// Valid for |x| < 2^24 (results below 2^-1075 come out as 0 through ldexp); no clamps, NaN in -> NaN out.
+__device__ __forceinline__ double fexp_t(double x, const MathTables* __restrict__ mt) {
+    const double MAGIC = 6755399441055744.0;                     // 1.5 * 2^52
+    const double t = fma(x, 92.332482616893656877, MAGIC);       // 64 / ln2; low word of t = round(64 x / ln2)
+    const double kd = t - MAGIC;
+    double r = fma(kd, -1.08304246932675596326e-02, x);          // ln2_hi / 64 (kd * hi exact)
+    r = fma(kd, -2.98158582698529328128e-12, r);                 // ln2_lo / 64
+    const int k = __double2loint(t);
+    const double T = mt->expt[k & 63];
+    double q = fma(r, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
+    q = fma(q, r, 1.66666666666666666667e-01);
+    q = fma(q, r, 0.5);
+    const double p = fma(r * r, q, r);                           // e^r - 1
+    return ldexp(fma(T, p, T), k >> 6);
+}
+
+// the same with the argument clamped to [-750, 709] (grid kernels: arguments are not pre-screened)
+__device__ __forceinline__ double fexp_c(double x, const MathTables* __restrict__ mt) {
+    return fexp_t(fmin(fmax(x, -750.0), 709.0), mt);
+}
+
+// ln(w / 2) for w in (0, 2]; w = 0 returns about -710 (finite).
+__device__ __forceinline__ double flog_half(double w, const MathTables* __restrict__ mt) {
+    const int hi = __double2hiint(w), lo = __double2loint(w);
+    const int e = ((hi >> 20) & 0x7ff) - 1024;                       // exponent of w/2
+    const int j = (hi >> 13) & 0x7f;
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);   // mantissa in [1, 2)
+    const double2 t = mt->logt[j];
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, -1.0 / 6.0, 0.2);
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -0.5);
+    const double r2 = r * r;
+    const double hi_part = fma((double)e, LF_LN2, t.y);
+    return hi_part + fma(p, r2, r);
+}
+
+// 1/sqrt(s), s >= 1: v_rsq_f64 seed (2^-24, measured) + one cubic step (error ~ e^3)
+__device__ __forceinline__ double frsqrt(double s) {
+    const double z0 = __builtin_amdgcn_rsq(s);
+    const double e = fma(-(s * z0), z0, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    return fma(z0, p * e, z0);
+}
+
+// 1/d for normal d: v_rcp_f64 seed (2^-24) + one cubic Newton step
+__device__ __forceinline__ double frcp(double d) {
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, y0, 1.0);
+    return fma(y0, fma(e, e, e), y0);
+}
+
+// copy the tables to LDS (call with all threads, then __syncthreads())
+__device__ __forceinline__ void load_tables(MathTables* mt) {
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) mt->logt[i] = make_double2(LOG_TABLE[2 * i], LOG_TABLE[2 * i + 1]);
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) mt->expt[i] = EXP_TABLE[i];
+}
 
 // 64-lane wavefront sum (no masks on CDNA: every lane takes part).
 __device__ __forceinline__ double wave_sum(double v) {

@@ -51,7 +51,7 @@ struct lf_ctx {
     size_t cap_partA = 0, cap_partB = 0;
     double *d_theta = nullptr, *d_out = nullptr, *d_outA = nullptr, *d_outB = nullptr;
     double *d_wrec = nullptr, *d_partA = nullptr, *d_partB = nullptr;
-    int* d_prior = nullptr;
+    int *d_wstat = nullptr, *d_wmode = nullptr;
     double *h_theta = nullptr, *h_out = nullptr;   // pinned staging
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the previous enqueue (workspace is shared)
@@ -107,13 +107,21 @@ int get_chunks(lf_ctx* c, int ch, ChunkTable** out) {
     return LF_OK;
 }
 
-int pick_src_chunk(const lf_ctx* c, int tiles) {
-    if (c->opt_src_chunk > 0) return (int)c->opt_src_chunk;
-    // enough workgroups to fill 256 CUs several times over, as few partials as that allows
-    const int64_t target_blocks = 4096;
-    int64_t ch = (c->N * (int64_t)tiles + target_blocks - 1) / target_blocks;
-    ch = ((ch + lf::BLOCK - 1) / lf::BLOCK) * lf::BLOCK;
-    return (int)std::min<int64_t>(std::max<int64_t>(ch, lf::BLOCK), 4096);
+// launch geometries of the per-source kernel: sources per lane (ST) x walkers per workgroup (TW)
+struct Geo {
+    int st, tw;
+};
+constexpr Geo GEO_BIG{8, 16}, GEO_SMALL{2, 8};
+constexpr int TW_GRID = 4;
+
+Geo pick_geometry(const lf_ctx* c, int B) {
+    if (c->opt_src_chunk == GEO_BIG.st * lf::BLOCK) return GEO_BIG;
+    if (c->opt_src_chunk == GEO_SMALL.st * lf::BLOCK) return GEO_SMALL;
+    // the big tile amortises loads and reductions best; fall back to the small one when it would
+    // leave the 256 CUs with fewer than ~4 workgroups each
+    const int64_t blocks = ((c->N + GEO_BIG.st * lf::BLOCK - 1) / (GEO_BIG.st * lf::BLOCK)) *
+                           (int64_t)((B + GEO_BIG.tw - 1) / GEO_BIG.tw);
+    return blocks >= 1024 ? GEO_BIG : GEO_SMALL;
 }
 
 int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
@@ -121,7 +129,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
         int nb = std::max(Bpad, c->cap_B * 2);
         LF_HIP(c, hipDeviceSynchronize());
         hipFree(c->d_theta); hipFree(c->d_out); hipFree(c->d_outA); hipFree(c->d_outB);
-        hipFree(c->d_wrec); hipFree(c->d_prior);
+        hipFree(c->d_wrec); hipFree(c->d_wstat); hipFree(c->d_wmode);
         if (c->h_theta) hipHostFree(c->h_theta);
         if (c->h_out) hipHostFree(c->h_out);
         c->cap_B = 0;
@@ -130,7 +138,8 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
         LF_HIP(c, hipMalloc((void**)&c->d_outA, (size_t)nb * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_outB, (size_t)nb * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_wrec, (size_t)nb * lf::REC * sizeof(double)));
-        LF_HIP(c, hipMalloc((void**)&c->d_prior, (size_t)nb * sizeof(int)));
+        LF_HIP(c, hipMalloc((void**)&c->d_wstat, (size_t)nb * sizeof(int)));
+        LF_HIP(c, hipMalloc((void**)&c->d_wmode, (size_t)nb * lf::MAXF * sizeof(int)));
         LF_HIP(c, hipHostMalloc((void**)&c->h_theta, (size_t)nb * 16 * sizeof(double), hipHostMallocDefault));
         LF_HIP(c, hipHostMalloc((void**)&c->h_out, (size_t)nb * 3 * sizeof(double), hipHostMallocDefault));
         c->cap_B = nb;
@@ -175,18 +184,27 @@ struct Prof {
 };
 
 // enqueue the four launches of one batched evaluation on `s`
+template <int VARIANT>
+void launch_srcsum(lf_ctx* c, Geo g, dim3 grid, hipStream_t s, const lf::SrcArrays& sa, int B, int nchA) {
+    using namespace lf;
+    if (g.st == GEO_BIG.st)
+        hipLaunchKernelGGL((lf_srcsum<VARIANT, GEO_BIG.st, GEO_BIG.tw>), grid, dim3(BLOCK), 0, s, c->kc, sa,
+                           c->d_wrec, c->d_wmode, B, c->d_partA, nchA);
+    else
+        hipLaunchKernelGGL((lf_srcsum<VARIANT, GEO_SMALL.st, GEO_SMALL.tw>), grid, dim3(BLOCK), 0, s, c->kc, sa,
+                           c->d_wrec, c->d_wmode, B, c->d_partA, nchA);
+}
+
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
             hipStream_t s) {
     using namespace lf;
-    const int tiles = (B + TW - 1) / TW;
-    const int Bpad = tiles * TW;
-    const int ch = pick_src_chunk(c, tiles);
+    const Geo geo = pick_geometry(c, B);
     ChunkTable* ct = nullptr;
-    int rc = get_chunks(c, ch, &ct);
+    int rc = get_chunks(c, geo.st * BLOCK, &ct);
     if (rc != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchB = (c->nnodes + BLOCK - 1) / BLOCK;
-    rc = ensure_workspace(c, Bpad, (size_t)Bpad * nchA, (size_t)Bpad * nchB);
+    rc = ensure_workspace(c, B, (size_t)B * nchA, (size_t)B * nchB);
     if (rc != LF_OK) return rc;
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
@@ -195,43 +213,38 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
 
     {
         Prof p(c, s, 0);
-        hipLaunchKernelGGL(lf_prepare, dim3((Bpad + 63) / 64), dim3(64), 0, s, c->kc, d_theta, B, Bpad,
-                           c->d_wrec, c->d_prior);
+        hipLaunchKernelGGL(lf_prepare, dim3((B + 63) / 64), dim3(64), 0, s, c->kc, d_theta, B, c->d_wrec,
+                           c->d_wstat, c->d_wmode);
     }
     SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, ct->d_start, ct->d_len, ct->d_field};
     NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->nnodes};
     if (nchA > 0) {
         Prof p(c, s, 1);
-        dim3 grid(nchA, tiles);
+        dim3 grid(nchA, (B + geo.tw - 1) / geo.tw);
         switch (c->kc.variant) {
-            case LF_FREE:
-                hipLaunchKernelGGL(lf_srcsum<LF_FREE>, grid, dim3(BLOCK), 0, s, c->kc, sa, c->d_wrec, c->d_partA, nchA);
-                break;
-            case LF_FIXCOMP:
-                hipLaunchKernelGGL(lf_srcsum<LF_FIXCOMP>, grid, dim3(BLOCK), 0, s, c->kc, sa, c->d_wrec, c->d_partA, nchA);
-                break;
-            default:
-                hipLaunchKernelGGL(lf_srcsum<LF_ZEVOL>, grid, dim3(BLOCK), 0, s, c->kc, sa, c->d_wrec, c->d_partA, nchA);
+            case LF_FREE: launch_srcsum<LF_FREE>(c, geo, grid, s, sa, B, nchA); break;
+            case LF_FIXCOMP: launch_srcsum<LF_FIXCOMP>(c, geo, grid, s, sa, B, nchA); break;
+            default: launch_srcsum<LF_ZEVOL>(c, geo, grid, s, sa, B, nchA);
         }
     }
     {
         Prof p(c, s, 2);
-        dim3 grid(nchB, tiles);
+        dim3 grid(nchB, (B + TW_GRID - 1) / TW_GRID);
         switch (c->kc.variant) {
             case LF_FREE:
-                hipLaunchKernelGGL(lf_gridsum<LF_FREE>, grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, c->d_partB, nchB);
+                hipLaunchKernelGGL((lf_gridsum<LF_FREE, TW_GRID>), grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, B, c->d_partB, nchB);
                 break;
             case LF_FIXCOMP:
-                hipLaunchKernelGGL(lf_gridsum<LF_FIXCOMP>, grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, c->d_partB, nchB);
+                hipLaunchKernelGGL((lf_gridsum<LF_FIXCOMP, TW_GRID>), grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, B, c->d_partB, nchB);
                 break;
             default:
-                hipLaunchKernelGGL(lf_gridsum<LF_ZEVOL>, grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, c->d_partB, nchB);
+                hipLaunchKernelGGL((lf_gridsum<LF_ZEVOL, TW_GRID>), grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, B, c->d_partB, nchB);
         }
     }
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           c->d_prior, B, d_out, d_outA, d_outB);
+                           c->d_wstat, B, d_out, d_outA, d_outB);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;
@@ -254,7 +267,8 @@ void free_ctx(lf_ctx* c) {
                       c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
     for (double* b : bufs)
         if (b) hipFree(b);
-    if (c->d_prior) hipFree(c->d_prior);
+    if (c->d_wstat) hipFree(c->d_wstat);
+    if (c->d_wmode) hipFree(c->d_wmode);
     if (c->h_theta) hipHostFree(c->h_theta);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -314,6 +328,43 @@ int build(lf_ctx* c, const lf_desc* d) {
             U[i] = d->z[i] * d->z[i];
         }
     }
+    // per-field extremes for the mode classification in lf_prepare
+    for (int f = 0; f < MAXF; ++f) {
+        kc.nsrc[f] = 0;
+        kc.pmax[f] = kc.lum_min[f] = kc.lum_max[f] = kc.a_min[f] = kc.u_min[f] = kc.u_max[f] = kc.z_lo[f] = kc.z_hi[f] = 0.0;
+    }
+    for (int f = 0; f < nf; ++f) {
+        const int64_t lo = d->field_ind[f], hi = d->field_ind[f + 1];
+        kc.nsrc[f] = (int)(hi - lo);
+        if (hi <= lo) continue;
+        double pmax = -HUGE_VAL, lmin = HUGE_VAL, lmax = -HUGE_VAL, amin = HUGE_VAL, amax = -HUGE_VAL, zlo = HUGE_VAL, zhi = -HUGE_VAL;
+        bool nan = false;
+        for (int64_t i = lo; i < hi; ++i) {
+            const double lum = d->lum[i];
+            lmin = std::fmin(lmin, lum);
+            lmax = std::fmax(lmax, lum);
+            nan = nan || std::isnan(lum);
+            if (d->variant != LF_ZEVOL) pmax = std::fmax(pmax, P[i]);
+            const double a = d->variant == LF_FREE ? d->logf[i] : (d->variant == LF_FIXCOMP ? a1[i] : P[i]);
+            amin = std::fmin(amin, a);
+            amax = std::fmax(amax, a);
+            nan = nan || std::isnan(a);
+            if (d->variant == LF_ZEVOL) {
+                zlo = std::fmin(zlo, d->z[i]);
+                zhi = std::fmax(zhi, d->z[i]);
+                nan = nan || std::isnan(d->z[i]);
+            }
+        }
+        if (nan) amin = -HUGE_VAL;                 // NaN input: force the careful path
+        kc.pmax[f] = pmax;
+        kc.lum_min[f] = lmin;
+        kc.lum_max[f] = lmax;
+        kc.a_min[f] = amin;
+        kc.u_min[f] = d->variant == LF_FREE ? std::pow(10.0, amin - LF_FREF) : 0.0;
+        kc.u_max[f] = d->variant == LF_FREE ? (nan ? HUGE_VAL : std::pow(10.0, amax - LF_FREF)) : 0.0;
+        kc.z_lo[f] = zlo;
+        kc.z_hi[f] = zhi;
+    }
     int rc;
     if ((rc = upload(c, &c->d_lum, d->lum, (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a1, a1.data(), (size_t)N)) != LF_OK) return rc;
@@ -361,8 +412,7 @@ int build(lf_ctx* c, const lf_desc* d) {
     if ((rc = upload(c, &c->d_a4, a4.data(), nn)) != LF_OK) return rc;
     LF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int mb = d->max_batch > 0 ? d->max_batch : 1024;
-    const int tiles = (mb + TW - 1) / TW;
-    return ensure_workspace(c, tiles * TW, 0, 0);
+    return ensure_workspace(c, mb, 0, 0);
 }
 
 }  // namespace
@@ -453,8 +503,7 @@ static int host_eval(lf_ctx* c, const double* theta, int B, double* out, double*
         return LF_ERR_ARG;
     }
     LF_HIP(c, hipSetDevice(c->device));
-    const int Bpad = ((B + TW - 1) / TW) * TW;
-    int rc = ensure_workspace(c, Bpad, 0, 0);
+    int rc = ensure_workspace(c, B, 0, 0);
     if (rc != LF_OK) return rc;
     const size_t tb = (size_t)B * c->kc.ndim * sizeof(double);
     std::memcpy(c->h_theta, theta, tb);
@@ -523,8 +572,8 @@ int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
 int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return LF_ERR_ARG;
     if (std::strcmp(key, "src_chunk") == 0) {
-        if (value < 0 || value % lf::BLOCK != 0 || value > (1 << 20)) {
-            c->err = "src_chunk must be a non-negative multiple of 256";
+        if (value != 0 && value != GEO_BIG.st * lf::BLOCK && value != GEO_SMALL.st * lf::BLOCK) {
+            c->err = "src_chunk must be 0 (auto), 512 or 2048";
             return LF_ERR_ARG;
         }
         c->opt_src_chunk = value;
