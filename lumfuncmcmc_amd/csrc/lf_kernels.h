@@ -57,6 +57,11 @@ struct KConst {
     double u_min[MAXF];       // FREE: 10^(min logf + 17)
     double u_max[MAXF];       // FREE: 10^(max logf + 17)
     double z_lo[MAXF], z_hi[MAXF];   // ZEVOL
+    // per-field sums for the closed-form part of piece A:
+    //   sum_i ln TrueLumFunc_i = n (ln ln10 + ln10 phi*) + c1 (sum(lum_i - 42) - n (L* - 42)) - Q sum P_i
+    double slc[MAXF];         // sum (lum_i - 42)
+    double sp[MAXF];          // sum 10^(lum_i - 42)
+    double som[MAXF];         // FIXCOMP/ZEVOL: sum ln(Om_arr_i)
 };
 
 // getQuadCoef, lumfuncmcmc_z.py:40-42, with the reference's operation order and no FMA contraction
@@ -94,7 +99,8 @@ __device__ inline void quad_range(double a, double b, double c, double lo, doubl
 // set_parameters_from_list + lnprior: lumfuncmcmc.py:327-358, lumfuncmcmc_z.py:339-362.
 // ----------------------------------------------------------------------------------------------
 __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
-                           double* __restrict__ wrec, int* __restrict__ wstat, int* __restrict__ wmode) {
+                           double* __restrict__ wrec, int* __restrict__ wstat, int* __restrict__ wmode,
+                           double* __restrict__ wbase) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= B) return;
     const double* th = theta + (size_t)w * kc.ndim;
@@ -103,6 +109,7 @@ __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
     int* mode = wmode + (size_t)w * MAXF;
     const double SAFE = -700.0;
     bool ok = true, neginf = false;
+    double base = 0.0;     // walker-only part of piece A (closed form), added back in lf_finalize
     if (kc.variant == LF_ZEVOL) {
         const double L1 = th[0], L2 = th[1], L3 = th[2], p1 = th[3], p2 = th[4], p3 = th[5];
         const double al = kc.fix_sch_al ? kc.sch_al0 : th[6];
@@ -129,6 +136,7 @@ __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
                 const double vb = pow(10.0, tmax);
                 const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
                 m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
+                base += kc.som[f];                 // sum_i ln Om_arr_i does not depend on theta
             }
             mode[f] = m;
         }
@@ -189,8 +197,15 @@ __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
             }
             if (m == MODE_NEGINF) neginf = true;
             mode[f] = m;
+            if (kc.nsrc[f] > 0) {
+                const double n = (double)kc.nsrc[f];
+                const double c0f = c0 + (kc.variant == LF_FREE ? kc.lnom0_src[f] : 0.0);
+                base += n * c0f + c1 * (kc.slc[f] - n * (Lstar - LF_LREF)) - Q * kc.sp[f] +
+                        (kc.variant == LF_FIXCOMP ? kc.som[f] : 0.0);
+            }
         }
     }
+    wbase[w] = base;
     wstat[w] = (ok ? STAT_PRIOR_OK : 0) | (neginf ? STAT_NEGINF : 0);
 }
 
@@ -211,12 +226,13 @@ struct WFree {   // wave-uniform walker constants of one (walker, field)
     double Lstar, c0f, c1, Q, alphaC, lF, V, lnom0;
 };
 
-__device__ __forceinline__ double term_free_fast(const WFree& w, double lum, double logf, double P, double U,
+// completeness part of the term, ln(fc) / (1 - e^(-f/f_tau)); the Schechter part and ln Omega_0 are
+// summed in closed form per walker (lf_prepare -> wbase)
+__device__ __forceinline__ double term_free_fast(const WFree& w, double logf, double U,
                                                  const MathTables* __restrict__ tab) {
-    const double lnT = fma(w.c1, lum - w.Lstar, w.c0f) - P * w.Q;          // ln TrueLumFunc + ln Omega_0
     const double lnfc = ln_fc_fast(w.alphaC * (logf - w.lF), tab);
-    const double d = 1.0 - fexp_t(-(U * w.V), tab);                        // expdecay, VmaxLumFunc.py:141
-    return fma(lnfc, frcp(d), lnT);
+    const double d = 1.0 - fexp_neg(U * w.V, tab);                         // expdecay, VmaxLumFunc.py:141
+    return lnfc * frcp(d);
 }
 
 __device__ __forceinline__ double term_free_careful(const WFree& w, double lum, double logf, double P, double U) {
@@ -229,7 +245,7 @@ __device__ __forceinline__ double term_free_careful(const WFree& w, double lum, 
     const double term = (lnT - w.lnom0) + lnOm;
     const bool bad = (v > LF_UNDERFLOW) | (lnT - w.lnom0 < -LF_UNDERFLOW) | (lnOm < -LF_UNDERFLOW) |
                      (term < -LF_UNDERFLOW) | (term != term);
-    return bad ? NEG_INF : term;
+    return bad ? NEG_INF : lnOm - w.lnom0;      // the rest of the term is in wbase
 }
 
 struct WZ {
@@ -276,11 +292,23 @@ struct SrcArrays {
 
 template <int VARIANT, int ST, int TW>
 __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, const double* __restrict__ wrec,
-                                                   const int* __restrict__ wmode, int B,
+                                                   const int* __restrict__ wmode, int B, int ntiles,
                                                    double* __restrict__ partial, int pstride) {
     __shared__ MathTables tab;
     __shared__ double red[TW * BLOCK];
-    const int c = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its
+    // own L2.  Renumber so that the ntiles workgroups that read the SAME chunk of the catalogue are
+    // consecutive on ONE XCD: the chunk is fetched from HBM once and served to the others from L2.
+    // (speed only - any placement gives the same result)
+    const int tid = threadIdx.x;
+    int c, tile;
+    {
+        const int nblk = gridDim.x, id = blockIdx.x;
+        const int q = nblk >> 3, rem = nblk & 7, xcd = id & 7;
+        const int wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+        c = wg / ntiles;
+        tile = wg - c * ntiles;
+    }
     const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
     const int w0 = tile * TW;
     const int nw = min(TW, B - w0);
@@ -314,21 +342,16 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, cons
                                r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
 #pragma unroll
                 for (int k = 0; k < ST; ++k)
-                    acc = fma(term_free_fast(wf, lum[k], a1[k], pp[k], uu[k], &tab), wgt[k], acc);
+                    acc = fma(term_free_fast(wf, a1[k], uu[k], &tab), wgt[k], acc);
             } else if (VARIANT == LF_FIXCOMP) {
-                const double Lstar = r[R_LSTAR], c0 = r[R_C0], c1 = r[R_C1], Q = r[R_Q];
-#pragma unroll
-                for (int k = 0; k < ST; ++k) {
-                    const double lnT = fma(c1, lum[k] - Lstar, c0) - pp[k] * Q;
-                    acc = fma(lnT + a1[k], wgt[k], acc);
-                }
+                // nothing left per source: piece A is the closed form in wbase
             } else {
                 const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
 #pragma unroll
                 for (int k = 0; k < ST; ++k) {
                     double v;
                     const double lnT = lnT_zevol<true>(wz, lum[k], a1[k], uu[k], v, &tab);
-                    acc = fma(lnT + pp[k], wgt[k], acc);
+                    acc = fma(lnT, wgt[k], acc);            // sum ln Om_arr_i is in wbase
                 }
             }
             red[w * BLOCK + tid] = acc;
@@ -351,14 +374,14 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, cons
                     const double lnT = fma(r[R_C1], lum[k] - r[R_LSTAR], r[R_C0]) - v;
                     term = lnT + a1[k];
                     const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
-                    term = bad ? NEG_INF : term;
+                    term = bad ? NEG_INF : 0.0;             // the value itself is in wbase
                 } else {
                     const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
                     double v;
                     const double lnT = lnT_zevol<false>(wz, lum[k], a1[k], uu[k], v, &tab);
                     term = lnT + pp[k];
                     const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
-                    term = bad ? NEG_INF : term;
+                    term = bad ? NEG_INF : lnT;
                 }
                 acc += wgt[k] != 0.0 ? term : 0.0;
             }
@@ -431,7 +454,8 @@ __global__ __launch_bounds__(BLOCK) void lf_gridsum(KConst kc, NodeArrays na, co
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,
                                                   const double* __restrict__ partB, int nchB, int strideB,
-                                                  const int* __restrict__ wstat, int B,
+                                                  const int* __restrict__ wstat,
+                                                  const double* __restrict__ wbase, int B,
                                                   double* __restrict__ out, double* __restrict__ outA,
                                                   double* __restrict__ outB) {
     const int w = blockIdx.x;
@@ -447,6 +471,7 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
     if (lane == 0) {
         const int st = wstat[w];
         const bool ok = (st & STAT_PRIOR_OK) != 0;
+        a += wbase[w];
         if ((st & STAT_NEGINF) || a != a) a = -__builtin_huge_val();
         double r = a - b;
         if (!ok || r != r) r = -__builtin_huge_val();

@@ -57,6 +57,22 @@ __device__ __forceinline__ double fexp_t(double x, const MathTables* __restrict_
     return ldexp(fma(T, p, T), k >> 6);
 }
 
+// e^(-u) for the completeness decay 1 - e^(-u), u >= 0.  One-constant reduction: the error of
+// ln2/64 as a double adds u * 1.1e-16 relative to e^(-u), i.e. at most 4e-17 absolute to 1 - e^(-u).
+__device__ __forceinline__ double fexp_neg(double u, const MathTables* __restrict__ mt) {
+    const double MAGIC = 6755399441055744.0;
+    const double t = fma(u, -92.332482616893656877, MAGIC);
+    const double kd = t - MAGIC;
+    const double r = fma(kd, -1.08304246962491454596e-02, -u);   // ln2 / 64
+    const int k = __double2loint(t);
+    const double T = mt->expt[k & 63];
+    double q = fma(r, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
+    q = fma(q, r, 1.66666666666666666667e-01);
+    q = fma(q, r, 0.5);
+    const double p = fma(r * r, q, r);
+    return ldexp(fma(T, p, T), k >> 6);
+}
+
 // the same with the argument clamped to [-750, 709] (grid kernels: arguments are not pre-screened)
 __device__ __forceinline__ double fexp_c(double x, const MathTables* __restrict__ mt) {
     return fexp_t(fmin(fmax(x, -750.0), 709.0), mt);

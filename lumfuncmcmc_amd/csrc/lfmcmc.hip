@@ -52,6 +52,7 @@ struct lf_ctx {
     double *d_theta = nullptr, *d_out = nullptr, *d_outA = nullptr, *d_outB = nullptr;
     double *d_wrec = nullptr, *d_partA = nullptr, *d_partB = nullptr;
     int *d_wstat = nullptr, *d_wmode = nullptr;
+    double* d_wbase = nullptr;
     double *h_theta = nullptr, *h_out = nullptr;   // pinned staging
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the previous enqueue (workspace is shared)
@@ -129,7 +130,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
         int nb = std::max(Bpad, c->cap_B * 2);
         LF_HIP(c, hipDeviceSynchronize());
         hipFree(c->d_theta); hipFree(c->d_out); hipFree(c->d_outA); hipFree(c->d_outB);
-        hipFree(c->d_wrec); hipFree(c->d_wstat); hipFree(c->d_wmode);
+        hipFree(c->d_wrec); hipFree(c->d_wstat); hipFree(c->d_wmode); hipFree(c->d_wbase);
         if (c->h_theta) hipHostFree(c->h_theta);
         if (c->h_out) hipHostFree(c->h_out);
         c->cap_B = 0;
@@ -140,6 +141,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
         LF_HIP(c, hipMalloc((void**)&c->d_wrec, (size_t)nb * lf::REC * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_wstat, (size_t)nb * sizeof(int)));
         LF_HIP(c, hipMalloc((void**)&c->d_wmode, (size_t)nb * lf::MAXF * sizeof(int)));
+        LF_HIP(c, hipMalloc((void**)&c->d_wbase, (size_t)nb * sizeof(double)));
         LF_HIP(c, hipHostMalloc((void**)&c->h_theta, (size_t)nb * 16 * sizeof(double), hipHostMallocDefault));
         LF_HIP(c, hipHostMalloc((void**)&c->h_out, (size_t)nb * 3 * sizeof(double), hipHostMallocDefault));
         c->cap_B = nb;
@@ -185,14 +187,14 @@ struct Prof {
 
 // enqueue the four launches of one batched evaluation on `s`
 template <int VARIANT>
-void launch_srcsum(lf_ctx* c, Geo g, dim3 grid, hipStream_t s, const lf::SrcArrays& sa, int B, int nchA) {
+void launch_srcsum(lf_ctx* c, Geo g, dim3 grid, int ntiles, hipStream_t s, const lf::SrcArrays& sa, int B, int nchA) {
     using namespace lf;
     if (g.st == GEO_BIG.st)
         hipLaunchKernelGGL((lf_srcsum<VARIANT, GEO_BIG.st, GEO_BIG.tw>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                           c->d_wrec, c->d_wmode, B, c->d_partA, nchA);
+                           c->d_wrec, c->d_wmode, B, ntiles, c->d_partA, nchA);
     else
         hipLaunchKernelGGL((lf_srcsum<VARIANT, GEO_SMALL.st, GEO_SMALL.tw>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                           c->d_wrec, c->d_wmode, B, c->d_partA, nchA);
+                           c->d_wrec, c->d_wmode, B, ntiles, c->d_partA, nchA);
 }
 
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
@@ -214,17 +216,18 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 0);
         hipLaunchKernelGGL(lf_prepare, dim3((B + 63) / 64), dim3(64), 0, s, c->kc, d_theta, B, c->d_wrec,
-                           c->d_wstat, c->d_wmode);
+                           c->d_wstat, c->d_wmode, c->d_wbase);
     }
     SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, ct->d_start, ct->d_len, ct->d_field};
     NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->nnodes};
     if (nchA > 0) {
         Prof p(c, s, 1);
-        dim3 grid(nchA, (B + geo.tw - 1) / geo.tw);
+        const int ntiles = (B + geo.tw - 1) / geo.tw;
+        dim3 grid((unsigned)nchA * ntiles);          // 1-D: lf_srcsum maps ids to (chunk, tile) per XCD
         switch (c->kc.variant) {
-            case LF_FREE: launch_srcsum<LF_FREE>(c, geo, grid, s, sa, B, nchA); break;
-            case LF_FIXCOMP: launch_srcsum<LF_FIXCOMP>(c, geo, grid, s, sa, B, nchA); break;
-            default: launch_srcsum<LF_ZEVOL>(c, geo, grid, s, sa, B, nchA);
+            case LF_FREE: launch_srcsum<LF_FREE>(c, geo, grid, ntiles, s, sa, B, nchA); break;
+            case LF_FIXCOMP: launch_srcsum<LF_FIXCOMP>(c, geo, grid, ntiles, s, sa, B, nchA); break;
+            default: launch_srcsum<LF_ZEVOL>(c, geo, grid, ntiles, s, sa, B, nchA);
         }
     }
     {
@@ -244,7 +247,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           c->d_wstat, B, d_out, d_outA, d_outB);
+                           c->d_wstat, c->d_wbase, B, d_out, d_outA, d_outB);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;
@@ -269,6 +272,7 @@ void free_ctx(lf_ctx* c) {
         if (b) hipFree(b);
     if (c->d_wstat) hipFree(c->d_wstat);
     if (c->d_wmode) hipFree(c->d_wmode);
+    if (c->d_wbase) hipFree(c->d_wbase);
     if (c->h_theta) hipHostFree(c->h_theta);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -331,7 +335,7 @@ int build(lf_ctx* c, const lf_desc* d) {
     // per-field extremes for the mode classification in lf_prepare
     for (int f = 0; f < MAXF; ++f) {
         kc.nsrc[f] = 0;
-        kc.pmax[f] = kc.lum_min[f] = kc.lum_max[f] = kc.a_min[f] = kc.u_min[f] = kc.u_max[f] = kc.z_lo[f] = kc.z_hi[f] = 0.0;
+        kc.pmax[f] = kc.lum_min[f] = kc.lum_max[f] = kc.a_min[f] = kc.u_min[f] = kc.u_max[f] = kc.z_lo[f] = kc.z_hi[f] = kc.slc[f] = kc.sp[f] = kc.som[f] = 0.0;
     }
     for (int f = 0; f < nf; ++f) {
         const int64_t lo = d->field_ind[f], hi = d->field_ind[f + 1];
@@ -339,8 +343,13 @@ int build(lf_ctx* c, const lf_desc* d) {
         if (hi <= lo) continue;
         double pmax = -HUGE_VAL, lmin = HUGE_VAL, lmax = -HUGE_VAL, amin = HUGE_VAL, amax = -HUGE_VAL, zlo = HUGE_VAL, zhi = -HUGE_VAL;
         bool nan = false;
+        long double slc = 0.0L, sp = 0.0L, som = 0.0L;
         for (int64_t i = lo; i < hi; ++i) {
             const double lum = d->lum[i];
+            slc += (long double)(lum - LF_LREF);
+            if (d->variant != LF_ZEVOL) sp += (long double)P[i];
+            if (d->variant == LF_FIXCOMP) som += (long double)a1[i];
+            if (d->variant == LF_ZEVOL) som += (long double)P[i];
             lmin = std::fmin(lmin, lum);
             lmax = std::fmax(lmax, lum);
             nan = nan || std::isnan(lum);
@@ -364,6 +373,9 @@ int build(lf_ctx* c, const lf_desc* d) {
         kc.u_max[f] = d->variant == LF_FREE ? (nan ? HUGE_VAL : std::pow(10.0, amax - LF_FREF)) : 0.0;
         kc.z_lo[f] = zlo;
         kc.z_hi[f] = zhi;
+        kc.slc[f] = (double)slc;
+        kc.sp[f] = (double)sp;
+        kc.som[f] = (double)som;
     }
     int rc;
     if ((rc = upload(c, &c->d_lum, d->lum, (size_t)N)) != LF_OK) return rc;
