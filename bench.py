@@ -25,13 +25,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 (spec; half of the 157.3 fp32 figure)
+FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 (spec; half of the 157.3 fp32 figure of MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
-# nominal fp64 flops per (walker, source) term of the factored FREE formulation, with the op
-# weights of SURVEY.md section 8d (exp/log 40, rsqrt/div 16, other VALU 2 per FMA-class op):
-# 1 log + 1 exp + 1 rsqrt + 1 div + 17 mul/add/fma  
-FLOPS_PER_TERM = {"free": 40 + 40 + 16 + 16 + 2 * 17, "fixcomp": 2 * 6, "zevol": 40 + 2 * 14}
-BYTES_PER_SOURCE = {"free": 16, "fixcomp": 8, "zevol": 16}
+# EXECUTED fp64 flops per (walker, source) term of the per-source kernel's fast loop, counted from
+# the compiler's assembly (profiles/isa_mix.py -> profiles/r01_isa_mix.txt): FMA = 2, any other fp64
+# VALU instruction = 1.  (The survey's nominal weights - exp/log = 40 flops - would put the same
+# run at ~100 % of peak; DESIGN.md section 4 explains why that figure is not used.)
+FLOPS_PER_TERM = {"free": 61.0, "zevol": 38.0, "fixcomp": 0.0}
+# issue cycles one wave spends per term (fp64 VALU 4, v_rcp/v_rsq_f64 16, 32-bit VALU 2.5; measured
+# rates in profiles/r01_ubench.txt), for the issue-utilisation figure
+CYCLES_PER_TERM = {"free": 203.0, "zevol": 108.0, "fixcomp": 0.0}
+# bytes the per-source kernel streams per source: lum, logf and the two hoisted powers (free);
+# lum, z, ln Om, z^2 (zevol).  SURVEY.md section 8d counts 16 B (lum, logf): the other 16 B buy two exp
+# per (source, walker tile) - HBM is not the binding roof.
+BYTES_PER_SOURCE = {"free": 32, "fixcomp": 24, "zevol": 32}
 
 
 def build_model(variant, nsrc, walkers, device):
@@ -160,11 +167,14 @@ def main():
                 traffic = None
         ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12
         ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
+        term_waves_per_s = terms / 64.0 / (avg_ms * 1e-3)
         roofline = {"bound": "valu_fp64", "kernel": "lf_srcsum<%s>" % args.variant, "achieved": ach_tf,
                     "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
-                    "terms_per_launch": terms, "flops_per_term_nominal": FLOPS_PER_TERM[args.variant],
+                    "terms_per_launch": terms, "flops_per_term_executed": FLOPS_PER_TERM[args.variant],
                     "terms_per_s": terms / (avg_ms * 1e-3),
+                    # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the term loop needs
+                    "valu_issue_frac_at_2p4GHz": term_waves_per_s * CYCLES_PER_TERM[args.variant] / (1024 * 2.4e9),
                     "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
                     "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items()}}

@@ -79,8 +79,9 @@ class EnsembleSampler(object):
                 partner = oth[self.random.randint(len(oth), size=half)]
                 prop = p[partner] - (p[partner] - p[act]) * zz[:, None]
                 newlp = self._lnprob(prop)
-                lnq = (self.ndim - 1.0) * np.log(zz) + newlp - lp[act]
-                acc = np.log(self.random.rand(half)) < lnq
+                with np.errstate(invalid="ignore"):          # -inf - -inf = nan: never accepted
+                    lnq = (self.ndim - 1.0) * np.log(zz) + newlp - lp[act]
+                    acc = np.log(self.random.rand(half)) < lnq
                 acc &= np.isfinite(newlp)
                 idx = act[acc]
                 p[idx] = prop[acc]

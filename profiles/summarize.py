@@ -1,0 +1,47 @@
+"""Turns the CSVs of profiles/collect.sh into the small summaries committed under profiles/:
+<tag>_kernel_stats.csv (rocprofv3 --stats rows of our kernels), <tag>_pmc.json (per-launch counter
+means) and an entry in hbm_traffic.json (HBM bytes per launch of the dominant kernel, FETCH_SIZE
+doubled as MI355X_MICROARCH.md prescribes for gfx950 streaming reads - calibrated on this kernel,
+see DESIGN.md section 6 - plus WRITE_SIZE).
+
+    python profiles/summarize.py gpurun_out/prof_<tag> <tag> <variant> <nsrc> <rows_per_call>
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag, variant, nsrc, rows = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+here = os.path.dirname(os.path.abspath(__file__))
+
+stats = os.path.join(src, "trace", "t_kernel_stats.csv")
+with open(stats) as f, open(os.path.join(here, "%s_kernel_stats.csv" % tag), "w") as g:
+    for i, line in enumerate(f):
+        if i == 0 or "lf::" in line:
+            g.write(line)
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob(os.path.join(src, "pmc_*", "p_counter_collection.csv")):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if "lf::" in k:
+            name = k.split("(")[0].replace("void ", "")
+            pmc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in pmc.items()}
+for k, cs in summary.items():
+    cs["_launches_sampled"] = len(next(iter(pmc[k].values())))
+json.dump(summary, open(os.path.join(here, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
+
+dom = [k for k in summary if "lf_srcsum" in k]
+if dom and "FETCH_SIZE" in summary[dom[0]]:
+    fetch_kb, write_kb = summary[dom[0]]["FETCH_SIZE"], summary[dom[0]].get("WRITE_SIZE", 0.0)
+    tf = os.path.join(here, "hbm_traffic.json")
+    d = json.load(open(tf)) if os.path.exists(tf) else {}
+    d["%s_n%d_b%d" % (variant, nsrc, rows)] = {
+        "kernel": dom[0], "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+        "fetch_correction": 2.0,
+        "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024 + write_kb * 1024, "source": "profiles/%s_pmc.json" % tag}
+    json.dump(d, open(tf, "w"), indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1)[:1500])

@@ -1,0 +1,81 @@
+"""The N>1 path on CPU: world_size-2 (and 3, ragged) gloo process groups.  The per-rank evaluator
+is the NumPy oracle (allowed in tests only) so that what is exercised here is the walker slicing,
+the padded all-gather and the lock-step sampler - the same code bench.py and the classes run
+over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lf_oracle as O
+    from lf_testlib import make_inputs
+    from lumfuncmcmc_amd import synth
+    from lumfuncmcmc_amd.dist import ShardedLnProb
+    from lumfuncmcmc_amd.sampler import EnsembleSampler
+    inp = make_inputs("fixcomp", 400, seed=3, S=24)
+    calls = []
+
+    def local_eval(t):                       # stands in for LFContext.lnprob_torch
+        calls.append(t.shape[0])
+        return torch.from_numpy(O.lnprob_batch(inp, t.numpy()))
+
+    sh = ShardedLnProb(local_eval, 3, torch.device("cpu"))
+    th = synth.walkers("fixcomp", B, seed=4)
+    got = sh(th)
+    ref = O.lnprob_batch(inp, th)
+    # a short lock-step chain: every rank runs the same sampler on the sharded callable
+    smp = EnsembleSampler(8, 3, sh, seed=11)
+    p, lp, _ = smp.run_mcmc(synth.walkers("fixcomp", 8, seed=5), 3)
+    q.put((rank, got, ref, list(calls), p, lp))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 16), (2, 7), (3, 10)])
+def test_sharded_lnprob_gloo(world, B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    per = (B + world - 1) // world
+    for rank, got, ref, calls, p, lp in res:
+        assert np.array_equal(got, ref)                 # every rank holds the whole block, in order
+        assert calls[0] == max(0, min(per, B - rank * per))    # and evaluated only its own slice
+        assert np.array_equal(p, res[0][4]) and np.array_equal(lp, res[0][5])   # chains stay identical
+
+
+def test_slice_bounds():
+    from lumfuncmcmc_amd.dist import slice_bounds
+    b, per = slice_bounds(10, 4)
+    assert per == 3 and b == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    b, per = slice_bounds(2, 4)
+    assert per == 1 and b == [(0, 1), (1, 2), (2, 2), (2, 2)]

@@ -220,3 +220,80 @@ def test_full_size_properties(variant, n, W):
         cf = (n * (np.log(np.log(10.0)) + np.log(10.0) * th[:, 1]) + c1 * (lum.sum() - n * th[:, 0])
               - 10.0 ** (-th[:, 0]) * np.sum(10.0 ** lum) + np.log(inp["Om_arr"]).sum())
         np.testing.assert_allclose(A, cf, rtol=1e-12)
+
+
+def test_faint_source_exercises_all_three_modes():
+    """One source far below the flux limit: depending on (Flim, alpha_C) a walker is FAST (bounds
+    clear), SLOW (bounds cannot exclude underflow: per-term checks decide) or really -inf."""
+    inp = make_inputs("free", 3000, seed=21)
+    inp["lum"] = inp["lum"].copy()
+    inp["lum"][5] = 39.75                      # ~1.9 dex below the 50% completeness flux of field 0
+    th = synth.walkers("free", 96, seed=22)
+    th[:, 3] = np.linspace(1.2, 5.9, 96)       # Flim of field 0
+    th[::3, 8] = 6.9                           # steep completeness: the faint source underflows
+    ref = O.lnprob_batch(inp, th)
+    assert np.isinf(ref).any() and np.isfinite(ref).sum() > 20
+    ctx = ctx_of(inp)
+    w = compare_rows(ctx.lnprob_batch(th), ref, inp, th, RTOL)
+    print("faint-source worst rel %.2e, -inf rows %d" % (w, np.isinf(ref).sum()))
+    ctx.close()
+
+
+def test_class_surface_free_fit_model():
+    """BASELINE config 1 shape: 1k sources, 32 walkers, 50 steps, through the class surface the
+    reference drivers use (constructor keywords of run_lumfuncmcmc.py:245-256)."""
+    from lumfuncmcmc_amd.model import LumFuncMCMC
+    cat = synth.catalogue(1000, seed=0)
+    fi = cat["field_ind"]
+    o = LumFuncMCMC(synth.split_fields(cat["z"], fi), flux=None, flux_e=None,
+                    lum=synth.split_fields(cat["lum"], fi), lum_e=synth.split_fields(cat["lum_e"], fi),
+                    Flim=list(synth.FLIM), alpha=synth.ALPHA_C, line_name="OIII",
+                    line_plot_name=r'[OIII] $\lambda 5007$', Omega_0=list(synth.OMEGA_0), nbins=50, nboot=100,
+                    sch_al=synth.SCH_AL, sch_al_lims=synth.SCH_AL_LIMS, Lstar=synth.LSTAR,
+                    Lstar_lims=synth.LSTAR_LIMS, phistar=synth.PHISTAR, phistar_lims=synth.PHISTAR_LIMS,
+                    Lc=synth.LC, Lh=synth.LH, nwalkers=32, nsteps=50, fix_sch_al=False, fix_comp=False,
+                    min_comp_frac=0.0, Flim_lims=synth.FLIM_LIMS, alpha_lims=synth.ALPHA_LIMS,
+                    field_names=np.array(["AEGIS", "COSMOS", "GOODSN", "GOODSS", "UDS"]), field_ind=fi,
+                    diff_rand=True)
+    th0 = np.array([42.5, -2.0, -1.49, 2.72, 3.61, 2.55, 3.31, 3.30, 4.56])
+    v = o.lnprob(th0)
+    assert isinstance(v, float) and abs(v - (-46587.950223002365)) < 1e-12 * 46588 * 10   # SURVEY App. C
+    g = np.load(os.path.join(GOLDEN, "free_n1000.npz"))
+    got = o.lnprob(g["theta"])                                     # (B, ndim) in one device call
+    inp = O.inputs_from_golden(g, "free")
+    compare_rows(got, g["lnprob"], inp, g["theta"], RTOL)
+    with pytest.raises(ValueError):
+        o.lnprob_fix_comp(th0[:3])
+    np.random.seed(5)
+    o.fit_model()
+    assert o.samples.shape[1] == 10 and o.samples.shape[0] % 32 == 0 and o.samples.shape[0] >= 32 * 25
+    assert o.chain.shape == (32, 50, 9)
+    fin = o.samples[np.isfinite(o.samples[:, -1])]
+    chk = o.lnprob(fin[:5, :-1])
+    np.testing.assert_allclose(chk, fin[:5, -1], rtol=1e-13)      # stored lnprob is what the path returns
+    assert len(o.get_param_names()) == 9 and o.get_init_walker_values().shape == (32, 9)
+    o.close()
+
+
+def test_class_surface_fixcomp_and_z():
+    from lumfuncmcmc_amd.model import LumFuncMCMC, LumFuncMCMCz
+    g = np.load(os.path.join(GOLDEN, "fixcomp_n1000.npz"))
+    fi = g["field_ind"]
+    kw = dict(lum=synth.split_fields(g["lum"], fi), lum_e=synth.split_fields(g["lum_e"], fi),
+              Flim=list(synth.FLIM), alpha=synth.ALPHA_C, Omega_0=list(synth.OMEGA_0), sch_al=synth.SCH_AL,
+              sch_al_lims=synth.SCH_AL_LIMS, Lstar=synth.LSTAR, Lstar_lims=synth.LSTAR_LIMS,
+              phistar=synth.PHISTAR, phistar_lims=synth.PHISTAR_LIMS, Lc=synth.LC, Lh=synth.LH, nwalkers=32,
+              nsteps=20, min_comp_frac=0.0, field_ind=fi)
+    o = LumFuncMCMC(synth.split_fields(g["z"], fi), fix_comp=True, Flim_lims=synth.FLIM_LIMS,
+                    alpha_lims=synth.ALPHA_LIMS, **kw)
+    inp = O.inputs_from_golden(g, "fixcomp")
+    compare_rows(o.lnprob_fix_comp(g["theta"]), g["lnprob"], inp, g["theta"], RTOL)
+    o.close()
+    g = np.load(os.path.join(GOLDEN, "zevol_n1000.npz"))
+    oz = LumFuncMCMCz(synth.split_fields(g["z"], fi), **kw)
+    inp = O.inputs_from_golden(g, "zevol")
+    compare_rows(oz.lnprob(g["theta"]), g["lnprob"], inp, g["theta"], RTOL)
+    np.random.seed(1)
+    oz.fit_model()
+    assert oz.samples.shape[1] == 8
+    oz.close()
