@@ -116,11 +116,11 @@ int lf_lnprob_batch_device(lf_ctx *ctx, const double *d_theta, int B, double *d_
  * get NaN in both.  Synchronous. */
 int lf_lnprob_pieces(lf_ctx *ctx, const double *theta, int B, double *outA, double *outB);
 
-/* Kernel timing for bench.py: when enabled, every launch is bracketed by hipEvents on the
- * stream it runs on.  lf_kernel_times reads and clears the accumulated totals:
- * ms[0..3] = {prepare, per-source sum (piece A), grid integral (piece B), finalize},
+/* Kernel timing for bench.py: level 1 brackets lf_main, level 2 every launch, with hipEvents on
+ * the stream the launch runs on (0 = off; each event pair costs a few microseconds of stream time).  lf_kernel_times reads and clears the accumulated totals:
+ * ms[0..3] = {lf_prepare, lf_main (per-source sum + grid integral, one launch), unused (0), lf_finalize},
  * launches[0..3] the launch counts.  Synchronises the recorded events. */
-int lf_set_profiling(lf_ctx *ctx, int enabled);
+int lf_set_profiling(lf_ctx *ctx, int level);
 int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
 
 /* Tuning knobs (performance only, never results beyond summation order):

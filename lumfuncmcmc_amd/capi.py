@@ -243,14 +243,15 @@ class LFContext(object):
             self.lnprob_batch_device(theta.data_ptr(), B, out.data_ptr(), stream)
         return out
 
-    def set_profiling(self, on):
-        self._check(self._lib.lf_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, level):
+        """0 off, 1 the main kernel only, 2 every launch (True = 2)."""
+        self._check(self._lib.lf_set_profiling(self._h, 2 if level is True else int(level)))
 
     def kernel_times(self):
         ms = (ctypes.c_double * 4)()
         n = (ctypes.c_int64 * 4)()
         self._check(self._lib.lf_kernel_times(self._h, ms, n))
-        names = ("prepare", "srcsum", "gridsum", "finalize")
+        names = ("prepare", "main", "unused", "finalize")
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
 
     def set_option(self, key, value):

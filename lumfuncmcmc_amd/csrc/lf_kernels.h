@@ -95,21 +95,40 @@ __device__ inline void quad_range(double a, double b, double c, double lo, doubl
 }
 
 // ----------------------------------------------------------------------------------------------
-// prepare: theta rows -> walker records, prior flag, per-(walker, field) mode.  One thread per walker.
-// set_parameters_from_list + lnprior: lumfuncmcmc.py:327-358, lumfuncmcmc_z.py:339-362.
+// prepare: theta rows -> walker records, prior flag, closed-form base, per-(walker, field) mode.
+// MAXF = 8 lanes per walker: lane f does field f (the expensive part: one careful Fleming evaluation
+// per field for the mode bound), every lane repeats the short walker-common part; the 8-lane groups
+// are combined with __shfl_xor.  The kernel is pure latency (B is a few hundred), so the point is a
+// short dependent chain.  set_parameters_from_list + lnprior: lumfuncmcmc.py:327-358,
+// lumfuncmcmc_z.py:339-362.
 // ----------------------------------------------------------------------------------------------
-__global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
-                           double* __restrict__ wrec, int* __restrict__ wstat, int* __restrict__ wmode,
-                           double* __restrict__ wbase) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= B) return;
+__device__ __forceinline__ double group8_sum(double v) {
+    v += __shfl_xor(v, 1, 8);
+    v += __shfl_xor(v, 2, 8);
+    v += __shfl_xor(v, 4, 8);
+    return v;
+}
+__device__ __forceinline__ int group8_or(int v) {
+    v |= __shfl_xor(v, 1, 8);
+    v |= __shfl_xor(v, 2, 8);
+    v |= __shfl_xor(v, 4, 8);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
+                                                 double* __restrict__ wrec, int* __restrict__ wstat,
+                                                 int* __restrict__ wmode, double* __restrict__ wbase) {
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wq = gt >> 3, f = gt & 7;
+    const bool live = wq < B;
+    const int w = live ? wq : B - 1;                 // idle groups replay the last walker, write nothing
+    const bool has_f = f < kc.nf;
     const double* th = theta + (size_t)w * kc.ndim;
     double* r = wrec + (size_t)w * REC;
-    for (int i = 0; i < REC; ++i) r[i] = 0.0;
-    int* mode = wmode + (size_t)w * MAXF;
     const double SAFE = -700.0;
-    bool ok = true, neginf = false;
-    double base = 0.0;     // walker-only part of piece A (closed form), added back in lf_finalize
+    bool ok = true;
+    int neginf = 0, m = MODE_FAST;
+    double base = 0.0;     // this lane's share of the walker-only part of piece A (closed form)
     if (kc.variant == LF_ZEVOL) {
         const double L1 = th[0], L2 = th[1], L3 = th[2], p1 = th[3], p2 = th[4], p3 = th[5];
         const double al = kc.fix_sch_al ? kc.sch_al0 : th[6];
@@ -123,90 +142,84 @@ __global__ void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
         quad_coef(L1, L2, L3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aL, bL, cL);
         quad_coef(p1, p2, p3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aP, bP, cP);
         const double c1 = LF_LN10 * (al + 1.0);
-        r[Z_AL] = aL; r[Z_BL] = bL; r[Z_CL] = cL;
-        r[Z_AP] = aP; r[Z_BP] = bP; r[Z_CP] = cP;
-        r[Z_C1] = c1;
-        for (int f = 0; f < kc.nf; ++f) {
-            int m = MODE_FAST;
-            if (kc.nsrc[f] > 0) {
-                double lsmn, lsmx, phmn, phmx;
-                quad_range(aL, bL, cL, kc.z_lo[f], kc.z_hi[f], lsmn, lsmx);
-                quad_range(aP, bP, cP, kc.z_lo[f], kc.z_hi[f], phmn, phmx);
-                const double tmax = kc.lum_max[f] - lsmn, tmin = kc.lum_min[f] - lsmx;
-                const double vb = pow(10.0, tmax);
-                const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
-                m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
-                base += kc.som[f];                 // sum_i ln Om_arr_i does not depend on theta
-            }
-            mode[f] = m;
+        if (live && f == 0) {
+            r[Z_AL] = aL; r[Z_BL] = bL; r[Z_CL] = cL;
+            r[Z_AP] = aP; r[Z_BP] = bP; r[Z_CP] = cP;
+            r[Z_C1] = c1;
+        }
+        if (has_f && kc.nsrc[f] > 0) {
+            double lsmn, lsmx, phmn, phmx;
+            quad_range(aL, bL, cL, kc.z_lo[f], kc.z_hi[f], lsmn, lsmx);
+            quad_range(aP, bP, cP, kc.z_lo[f], kc.z_hi[f], phmn, phmx);
+            const double tmax = kc.lum_max[f] - lsmn, tmin = kc.lum_min[f] - lsmx;
+            const double vb = pow(10.0, tmax);
+            const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
+            m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
+            base = kc.som[f];                      // sum_i ln Om_arr_i does not depend on theta
         }
     } else {
         const double Lstar = th[0], phistar = th[1];
         int k = 2;
         const double al = kc.fix_sch_al ? kc.sch_al0 : th[k++];
-        double alphaC = kc.alpha0;
-        double Flim[MAXF];
-        for (int f = 0; f < kc.nf; ++f) Flim[f] = kc.flim0[f];
-        if (kc.variant == LF_FREE) {
-            for (int f = 0; f < kc.nf; ++f) Flim[f] = th[k + f];
-            alphaC = th[k + kc.nf];
-        }
+        const double alphaC = kc.variant == LF_FREE ? th[k + kc.nf] : kc.alpha0;
         // inclusive box on all five named parameters, fixed ones too (lumfuncmcmc.py:346-354)
         ok = ok && (Lstar >= kc.lims[LF_LIM_LSTAR][0]) && (Lstar <= kc.lims[LF_LIM_LSTAR][1]);
         ok = ok && (phistar >= kc.lims[LF_LIM_PHISTAR][0]) && (phistar <= kc.lims[LF_LIM_PHISTAR][1]);
         ok = ok && (al >= kc.lims[LF_LIM_SCH_AL][0]) && (al <= kc.lims[LF_LIM_SCH_AL][1]);
-        for (int f = 0; f < kc.nf; ++f)
-            ok = ok && (Flim[f] >= kc.lims[LF_LIM_FLIM][0]) && (Flim[f] <= kc.lims[LF_LIM_FLIM][1]);
         ok = ok && (alphaC >= kc.lims[LF_LIM_ALPHA][0]) && (alphaC <= kc.lims[LF_LIM_ALPHA][1]);
         const double c0 = LF_LNLN10 + LF_LN10 * phistar, c1 = LF_LN10 * (al + 1.0);
         const double Q = pow(10.0, LF_LREF - Lstar);
-        r[R_LSTAR] = Lstar;
-        r[R_C0] = c0;
-        r[R_C1] = c1;
-        r[R_Q] = Q;
-        double tenb = 1.0;
-        if (kc.variant == LF_FREE) {
+        if (live && f == 0) {
+            r[R_LSTAR] = Lstar;
+            r[R_C0] = c0;
+            r[R_C1] = c1;
+            r[R_Q] = Q;
             r[R_ALPHAC] = alphaC;
-            const double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
-            tenb = pow(10.0, b);
         }
-        for (int f = 0; f < kc.nf; ++f) {
+        if (has_f) {
+            const double Flim = kc.variant == LF_FREE ? th[k + f] : kc.flim0[f];
+            ok = ok && (Flim >= kc.lims[LF_LIM_FLIM][0]) && (Flim <= kc.lims[LF_LIM_FLIM][1]);
             double lF = 0.0, V = 0.0;
             if (kc.variant == LF_FREE) {
-                lF = log10(1.0e-17 * Flim[f]);
-                V = 1.0 / (Flim[f] * tenb);
-                r[R_LF + f] = lF;
-                r[R_V + f] = V;
+                const double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
+                lF = log10(1.0e-17 * Flim);
+                V = 1.0 / (Flim * pow(10.0, b));
+                if (live) {
+                    r[R_LF + f] = lF;
+                    r[R_V + f] = V;
+                }
             }
-            int m = MODE_FAST;
             if (kc.nsrc[f] > 0) {
                 const double vmax = kc.pmax[f] * Q;       // the very product the kernels form for that source
                 const double tlo = kc.lum_min[f] - Lstar, thi = kc.lum_max[f] - Lstar;
                 const double lbT = c0 + fmin(c1 * tlo, c1 * thi) - vmax;
                 if (vmax > LF_UNDERFLOW) {
                     m = MODE_NEGINF;
+                    neginf = 1;
                 } else if (kc.variant == LF_FREE) {
                     const double num = alphaC * (kc.a_min[f] - lF);
                     const double lnfc = log(0.5 * (1.0 + num * rsqrt(fma(num, num, 1.0))));
                     const double lnOm = kc.lnom0_src[f] + lnfc / (1.0 - exp(-kc.u_min[f] * V));
-                    // fexp_t takes |x| < 2^24 unclamped: screen the largest f / f_tau of the field as well
+                    // fexp_neg takes |x| < 2^24 unclamped: screen the largest f / f_tau of the field as well
                     m = (lbT > SAFE && lnOm > SAFE && lbT + lnOm > SAFE && kc.u_max[f] * V < 1.0e6) ? MODE_FAST : MODE_SLOW;
                 } else {
                     m = (lbT > SAFE && lbT + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
                 }
-            }
-            if (m == MODE_NEGINF) neginf = true;
-            mode[f] = m;
-            if (kc.nsrc[f] > 0) {
                 const double n = (double)kc.nsrc[f];
                 const double c0f = c0 + (kc.variant == LF_FREE ? kc.lnom0_src[f] : 0.0);
-                base += n * c0f + c1 * (kc.slc[f] - n * (Lstar - LF_LREF)) - Q * kc.sp[f] +
-                        (kc.variant == LF_FIXCOMP ? kc.som[f] : 0.0);
+                base = n * c0f + c1 * (kc.slc[f] - n * (Lstar - LF_LREF)) - Q * kc.sp[f] +
+                       (kc.variant == LF_FIXCOMP ? kc.som[f] : 0.0);
             }
         }
     }
-    wbase[w] = base;
-    wstat[w] = (ok ? STAT_PRIOR_OK : 0) | (neginf ? STAT_NEGINF : 0);
+    if (live && has_f) wmode[(size_t)w * MAXF + f] = m;
+    base = group8_sum(base);
+    const int bad = group8_or(ok ? 0 : 1);
+    neginf = group8_or(neginf);
+    if (live && f == 0) {
+        wbase[w] = base;
+        wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -232,7 +245,7 @@ __device__ __forceinline__ double term_free_fast(const WFree& w, double logf, do
                                                  const MathTables* __restrict__ tab) {
     const double lnfc = ln_fc_fast(w.alphaC * (logf - w.lF), tab);
     const double d = 1.0 - fexp_neg(U * w.V, tab);                         // expdecay, VmaxLumFunc.py:141
-    return lnfc * frcp(d);
+    return lnfc * frcp(d);                                                  // (fused with the += by the compiler)
 }
 
 __device__ __forceinline__ double term_free_careful(const WFree& w, double lum, double logf, double P, double U) {
@@ -291,11 +304,10 @@ struct SrcArrays {
 };
 
 template <int VARIANT, int ST, int TW>
-__global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, const double* __restrict__ wrec,
-                                                   const int* __restrict__ wmode, int B, int ntiles,
-                                                   double* __restrict__ partial, int pstride) {
-    __shared__ MathTables tab;
-    __shared__ double red[TW * BLOCK];
+__device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& sa, const double* __restrict__ wrec,
+                                            const int* __restrict__ wmode, int B, int ntiles, int id, int nblk,
+                                            double* __restrict__ partial, int pstride,
+                                            const MathTables& tab, double* __restrict__ red) {
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its
     // own L2.  Renumber so that the ntiles workgroups that read the SAME chunk of the catalogue are
     // consecutive on ONE XCD: the chunk is fetched from HBM once and served to the others from L2.
@@ -303,7 +315,6 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, cons
     const int tid = threadIdx.x;
     int c, tile;
     {
-        const int nblk = gridDim.x, id = blockIdx.x;
         const int q = nblk >> 3, rem = nblk & 7, xcd = id & 7;
         const int wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
         c = wg / ntiles;
@@ -312,7 +323,6 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, cons
     const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
     const int w0 = tile * TW;
     const int nw = min(TW, B - w0);
-    load_tables(&tab);
 
     // items -> registers (lanes past the end replay the chunk's first source with weight 0)
     double lum[ST], a1[ST], pp[ST], uu[ST], wgt[ST];
@@ -325,11 +335,16 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, cons
         a1[k] = sa.a1[g];
         pp[k] = sa.P[g];
         uu[k] = VARIANT == LF_FIXCOMP ? 0.0 : sa.U[g];
+        if (VARIANT == LF_FREE && i >= n) {
+            // padding lanes of the FAST loop: a source so bright that fc = 1 and the decay is 1, i.e.
+            // ln(fc)/decay = 0 to within 2e-16 - cheaper than a weight multiply on every term
+            a1[k] = 1.0e30;
+            uu[k] = 1.0e4;
+        }
     }
     int mode = MODE_FAST;
     for (int w = 0; w < nw; ++w) mode = max(mode, wmode[(size_t)(w0 + w) * MAXF + fld]);
     mode = __builtin_amdgcn_readfirstlane(mode);
-    __syncthreads();
 
     const double NEG_INF = -__builtin_huge_val();
     if (mode == MODE_FAST) {
@@ -341,8 +356,7 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, cons
                 const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
                                r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
 #pragma unroll
-                for (int k = 0; k < ST; ++k)
-                    acc = fma(term_free_fast(wf, a1[k], uu[k], &tab), wgt[k], acc);
+                for (int k = 0; k < ST; ++k) acc += term_free_fast(wf, a1[k], uu[k], &tab);
             } else if (VARIANT == LF_FIXCOMP) {
                 // nothing left per source: piece A is the closed form in wbase
             } else {
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void lf_srcsum(KConst kc, SrcArrays sa, cons
                 if (VARIANT == LF_FREE) {
                     const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
                                    r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
-                    term = term_free_careful(wf, lum[k], a1[k], pp[k], uu[k]);
+                    term = term_free_careful(wf, lum[k], wgt[k] != 0.0 ? a1[k] : 0.0, pp[k], wgt[k] != 0.0 ? uu[k] : 1.0);
                 } else if (VARIANT == LF_FIXCOMP) {
                     const double v = pp[k] * r[R_Q];
                     const double lnT = fma(r[R_C1], lum[k] - r[R_LSTAR], r[R_C0]) - v;
@@ -407,20 +421,18 @@ struct NodeArrays {
 };
 
 template <int VARIANT, int TW>
-__global__ __launch_bounds__(BLOCK) void lf_gridsum(KConst kc, NodeArrays na, const double* __restrict__ wrec,
-                                                    int B, double* __restrict__ partial, int pstride) {
-    __shared__ MathTables tab;
-    __shared__ double red[TW * BLOCK];
-    const int c = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays& na, const double* __restrict__ wrec,
+                                             int B, int ntiles, int id, double* __restrict__ partial, int pstride,
+                                             const MathTables& tab, double* __restrict__ red) {
+    const int tid = threadIdx.x;
+    const int c = id / ntiles, tile = id - c * ntiles;
     const int w0 = tile * TW;
     const int nw = min(TW, B - w0);
-    load_tables(&tab);
     const int gi = c * BLOCK + tid;
     const bool valid = gi < na.nnodes;
     const int g = valid ? gi : 0;
     const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0;
     const double a3 = na.a3[g], a4 = na.a4[g];
-    __syncthreads();
 #pragma unroll 1
     for (int w = 0; w < nw; ++w) {
         const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
@@ -449,6 +461,30 @@ __global__ __launch_bounds__(BLOCK) void lf_gridsum(KConst kc, NodeArrays na, co
 }
 
 // ----------------------------------------------------------------------------------------------
+// lf_main: pieces A and B in ONE launch.  Workgroups [0, nblkB) integrate the grid (piece B),
+// the rest sum the catalogue (piece A); both kinds take about the same time per workgroup
+// at the big geometry (TW walkers x 256 items); the small geometry gives the grid part TWB = 2 walkers
+// per workgroup so that a small batch still spreads over the chip.  B first: it never forms the tail.
+// ----------------------------------------------------------------------------------------------
+template <int VARIANT, int ST, int TW, int TWB>
+__global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeArrays na,
+                                                 const double* __restrict__ wrec, const int* __restrict__ wmode,
+                                                 int B, int ntiles, int ntilesB, int nblkB,
+                                                 double* __restrict__ partA, int strideA,
+                                                 double* __restrict__ partB, int strideB) {
+    __shared__ MathTables tab;
+    __shared__ double red[(TW > TWB ? TW : TWB) * BLOCK];
+    load_tables(&tab);
+    __syncthreads();
+    const int id = blockIdx.x;
+    if (id < nblkB)
+        gridsum_body<VARIANT, TWB>(kc, na, wrec, B, ntilesB, id, partB, strideB, tab, red);
+    else
+        srcsum_body<VARIANT, ST, TW>(kc, sa, wrec, wmode, B, ntiles, id - nblkB, (int)gridDim.x - nblkB, partA,
+                                     strideA, tab, red);
+}
+
+// ----------------------------------------------------------------------------------------------
 // finalize: one wave per walker; fixed-order sum of the partials; lnprob = lnprior + A - B.
 // lumfuncmcmc.py:378, :403-409.  Never NaN (emcee raises on NaN): NaN -> -inf.
 // ----------------------------------------------------------------------------------------------
@@ -464,8 +500,18 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
     double a = 0.0, b = 0.0;
     const double* pa = partA + (size_t)w * strideA;
     const double* pb = partB + (size_t)w * strideB;
-    for (int c = lane; c < nchA; c += 64) a += pa[c];
-    for (int c = lane; c < nchB; c += 64) b += pb[c];
+    // four independent running sums per lane so that the loads are in flight together (latency kernel)
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = lane;
+    for (; c + 192 < nchA; c += 256) {
+        a += pa[c];
+        a1 += pa[c + 64];
+        a2 += pa[c + 128];
+        a3 += pa[c + 192];
+    }
+    for (; c < nchA; c += 64) a += pa[c];
+    a = (a + a1) + (a2 + a3);
+    for (c = lane; c < nchB; c += 64) b += pb[c];
     a = wave_sum(a);
     b = wave_sum(b);
     if (lane == 0) {

@@ -58,7 +58,7 @@ struct lf_ctx {
     hipStream_t last_stream = nullptr;   // stream of the previous enqueue (workspace is shared)
     bool any_enqueued = false;
     // profiling
-    bool profiling = false;
+    int profiling = 0;   // 0 off, 1 lf_main only, 2 every launch
     std::vector<EventPair> events;
     double acc_ms[4] = {0, 0, 0, 0};
     int64_t acc_n[4] = {0, 0, 0, 0};
@@ -110,10 +110,9 @@ int get_chunks(lf_ctx* c, int ch, ChunkTable** out) {
 
 // launch geometries of the per-source kernel: sources per lane (ST) x walkers per workgroup (TW)
 struct Geo {
-    int st, tw;
+    int st, tw, twb;     // sources per lane, walkers per source workgroup, walkers per grid workgroup
 };
-constexpr Geo GEO_BIG{8, 16}, GEO_SMALL{2, 8};
-constexpr int TW_GRID = 4;
+constexpr Geo GEO_BIG{8, 16, 16}, GEO_SMALL{2, 8, 2};
 
 Geo pick_geometry(const lf_ctx* c, int B) {
     if (c->opt_src_chunk == GEO_BIG.st * lf::BLOCK) return GEO_BIG;
@@ -169,7 +168,7 @@ struct Prof {
     int kind;
     EventPair ep{};
     bool on;
-    Prof(lf_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling) {
+    Prof(lf_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling >= 2 || (c_->profiling == 1 && k == 1)) {
         if (on) {
             hipEventCreate(&ep.a);
             hipEventCreate(&ep.b);
@@ -185,16 +184,18 @@ struct Prof {
     }
 };
 
-// enqueue the four launches of one batched evaluation on `s`
+// enqueue the three launches of one batched evaluation on `s`: prepare -> main (A and B) -> finalize
 template <int VARIANT>
-void launch_srcsum(lf_ctx* c, Geo g, dim3 grid, int ntiles, hipStream_t s, const lf::SrcArrays& sa, int B, int nchA) {
+void launch_main(lf_ctx* c, Geo g, dim3 grid, int ntiles, int ntilesB, int nblkB, hipStream_t s,
+                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
     using namespace lf;
     if (g.st == GEO_BIG.st)
-        hipLaunchKernelGGL((lf_srcsum<VARIANT, GEO_BIG.st, GEO_BIG.tw>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                           c->d_wrec, c->d_wmode, B, ntiles, c->d_partA, nchA);
+        hipLaunchKernelGGL((lf_main<VARIANT, GEO_BIG.st, GEO_BIG.tw, GEO_BIG.twb>), grid, dim3(BLOCK), 0, s, c->kc,
+                           sa, na, c->d_wrec, c->d_wmode, B, ntiles, ntilesB, nblkB, c->d_partA, nchA, c->d_partB, nchB);
     else
-        hipLaunchKernelGGL((lf_srcsum<VARIANT, GEO_SMALL.st, GEO_SMALL.tw>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                           c->d_wrec, c->d_wmode, B, ntiles, c->d_partA, nchA);
+        hipLaunchKernelGGL((lf_main<VARIANT, GEO_SMALL.st, GEO_SMALL.tw, GEO_SMALL.twb>), grid, dim3(BLOCK), 0, s,
+                           c->kc, sa, na, c->d_wrec, c->d_wmode, B, ntiles, ntilesB, nblkB, c->d_partA, nchA,
+                           c->d_partB, nchB);
 }
 
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
@@ -206,7 +207,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     if (rc != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchB = (c->nnodes + BLOCK - 1) / BLOCK;
-    rc = ensure_workspace(c, B, (size_t)B * nchA, (size_t)B * nchB);
+    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * nchB);
     if (rc != LF_OK) return rc;
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
@@ -215,33 +216,21 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
 
     {
         Prof p(c, s, 0);
-        hipLaunchKernelGGL(lf_prepare, dim3((B + 63) / 64), dim3(64), 0, s, c->kc, d_theta, B, c->d_wrec,
+        hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, d_theta, B, c->d_wrec,
                            c->d_wstat, c->d_wmode, c->d_wbase);
     }
     SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, ct->d_start, ct->d_len, ct->d_field};
     NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->nnodes};
-    if (nchA > 0) {
+    {
         Prof p(c, s, 1);
         const int ntiles = (B + geo.tw - 1) / geo.tw;
-        dim3 grid((unsigned)nchA * ntiles);          // 1-D: lf_srcsum maps ids to (chunk, tile) per XCD
+        const int ntilesB = (B + geo.twb - 1) / geo.twb;
+        const int nblkB = nchB * ntilesB;
+        dim3 grid((unsigned)(nblkB + nchA * ntiles));     // 1-D: B workgroups first, then A (chunk, tile) per XCD
         switch (c->kc.variant) {
-            case LF_FREE: launch_srcsum<LF_FREE>(c, geo, grid, ntiles, s, sa, B, nchA); break;
-            case LF_FIXCOMP: launch_srcsum<LF_FIXCOMP>(c, geo, grid, ntiles, s, sa, B, nchA); break;
-            default: launch_srcsum<LF_ZEVOL>(c, geo, grid, ntiles, s, sa, B, nchA);
-        }
-    }
-    {
-        Prof p(c, s, 2);
-        dim3 grid(nchB, (B + TW_GRID - 1) / TW_GRID);
-        switch (c->kc.variant) {
-            case LF_FREE:
-                hipLaunchKernelGGL((lf_gridsum<LF_FREE, TW_GRID>), grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, B, c->d_partB, nchB);
-                break;
-            case LF_FIXCOMP:
-                hipLaunchKernelGGL((lf_gridsum<LF_FIXCOMP, TW_GRID>), grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, B, c->d_partB, nchB);
-                break;
-            default:
-                hipLaunchKernelGGL((lf_gridsum<LF_ZEVOL, TW_GRID>), grid, dim3(BLOCK), 0, s, c->kc, na, c->d_wrec, B, c->d_partB, nchB);
+            case LF_FREE: launch_main<LF_FREE>(c, geo, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, geo, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+            default: launch_main<LF_ZEVOL>(c, geo, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB);
         }
     }
     {
@@ -555,7 +544,7 @@ int lf_lnprob_pieces(lf_ctx* c, const double* theta, int B, double* outA, double
 
 int lf_set_profiling(lf_ctx* c, int enabled) {
     if (!c) return LF_ERR_ARG;
-    c->profiling = enabled != 0;
+    c->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return LF_OK;
 }
 

@@ -53,7 +53,7 @@ def mix(lines):
 def main():
     s = assembly()
     for name, lines in kernels(s):
-        m = re.search(r"lf_srcsumILi(\d)ELi(\d+)ELi(\d+)", name)
+        m = re.search(r"lf_(?:srcsum|main)ILi(\d)ELi(\d+)ELi(\d+)", name)
         if not m:
             continue
         variant, st = int(m.group(1)), int(m.group(2))
@@ -67,7 +67,7 @@ def main():
             other = sum(fp64.values()) - fma
             ints = sum(v for k, v in c.items() if k.startswith("v_") and "f64" not in k)
             lds = sum(v for k, v in c.items() if k.startswith("ds_read"))
-            print("lf_srcsum<variant %d, ST %d>  fast loop, per (walker, source) term:" % (variant, st))
+            print("lf_main<variant %d, ST %d>  loop of %d lines, per item (term or grid node-field):" % (variant, st, b - a))
             print("   fp64 fma %.2f   other fp64 VALU %.2f   32-bit VALU %.2f   LDS reads %.2f" % (fma / st, other / st, ints / st, lds / st))
             print("   executed fp64 flops/term (fma = 2, other = 1): %.1f" % ((2 * fma + other) / st))
             print("   issue cycles/term-wave (fp64 4, rcp/rsq 16, 32-bit ~2.5): %.0f" % (

@@ -34,7 +34,7 @@ for k, cs in summary.items():
     cs["_launches_sampled"] = len(next(iter(pmc[k].values())))
 json.dump(summary, open(os.path.join(here, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
 
-dom = [k for k in summary if "lf_srcsum" in k]
+dom = [k for k in summary if "lf_main" in k or "lf_srcsum" in k]
 if dom and "FETCH_SIZE" in summary[dom[0]]:
     fetch_kb, write_kb = summary[dom[0]]["FETCH_SIZE"], summary[dom[0]].get("WRITE_SIZE", 0.0)
     tf = os.path.join(here, "hbm_traffic.json")
