@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--walkers", type=int, default=256, help="walkers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--src-chunk", type=int, default=0)
+    ap.add_argument("--geometry", type=int, default=-1)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
     args = ap.parse_args()
 
@@ -101,18 +103,23 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from lumfuncmcmc_amd.dist import ShardedLnProb
     W = args.walkers                       # per GPU
     half = W // 2
     model = build_model(args.variant, args.nsrc, W * world, local)
     ctx = model.context()
-    if args.src_chunk:
-        ctx.set_option("src_chunk", args.src_chunk)
+    if args.geometry >= 0:
+        ctx.set_option("geometry", args.geometry)
     ndim = ctx.ndim
     from lumfuncmcmc_amd import synth
     # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled

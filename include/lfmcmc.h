@@ -124,7 +124,8 @@ int lf_set_profiling(lf_ctx *ctx, int level);
 int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
 
 /* Tuning knobs (performance only, never results beyond summation order):
- * key "src_chunk" (sources per workgroup: 512, 2048, or 0 = chosen from N and B). */
+ * key "geometry": index of the launch geometry (sources per lane x walkers per workgroup),
+ * -1 = chosen from N and B. */
 int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
 
 /* Last error message of this context (or of lf_create when ctx == NULL).  Never NULL. */

@@ -45,7 +45,7 @@ struct lf_ctx {
     double *d_lum = nullptr, *d_a1 = nullptr, *d_P = nullptr, *d_U = nullptr;
     double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr;
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
-    int64_t opt_src_chunk = 0;
+    int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     // workspace
     int cap_B = 0;                      // padded walker capacity
     size_t cap_partA = 0, cap_partB = 0;
@@ -112,16 +112,17 @@ int get_chunks(lf_ctx* c, int ch, ChunkTable** out) {
 struct Geo {
     int st, tw, twb;     // sources per lane, walkers per source workgroup, walkers per grid workgroup
 };
-constexpr Geo GEO_BIG{8, 16, 16}, GEO_SMALL{2, 8, 2};
+// instantiated geometries; [0] and [1] are the defaults for large and small problems
+constexpr Geo GEOS[] = {{8, 16, 16}, {2, 8, 2}, {8, 8, 8}, {8, 4, 4}, {4, 8, 4}, {4, 4, 4}};
+constexpr int NGEO = sizeof(GEOS) / sizeof(GEOS[0]);
 
-Geo pick_geometry(const lf_ctx* c, int B) {
-    if (c->opt_src_chunk == GEO_BIG.st * lf::BLOCK) return GEO_BIG;
-    if (c->opt_src_chunk == GEO_SMALL.st * lf::BLOCK) return GEO_SMALL;
+int pick_geometry(const lf_ctx* c, int B) {
+    if (c->opt_geometry >= 0 && c->opt_geometry < NGEO) return (int)c->opt_geometry;
     // the big tile amortises loads and reductions best; fall back to the small one when it would
     // leave the 256 CUs with fewer than ~4 workgroups each
-    const int64_t blocks = ((c->N + GEO_BIG.st * lf::BLOCK - 1) / (GEO_BIG.st * lf::BLOCK)) *
-                           (int64_t)((B + GEO_BIG.tw - 1) / GEO_BIG.tw);
-    return blocks >= 1024 ? GEO_BIG : GEO_SMALL;
+    const int64_t blocks = ((c->N + GEOS[0].st * lf::BLOCK - 1) / (GEOS[0].st * lf::BLOCK)) *
+                           (int64_t)((B + GEOS[0].tw - 1) / GEOS[0].tw);
+    return blocks >= 1024 ? 0 : 1;
 }
 
 int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
@@ -185,23 +186,32 @@ struct Prof {
 };
 
 // enqueue the three launches of one batched evaluation on `s`: prepare -> main (A and B) -> finalize
-template <int VARIANT>
-void launch_main(lf_ctx* c, Geo g, dim3 grid, int ntiles, int ntilesB, int nblkB, hipStream_t s,
-                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
+template <int VARIANT, int GI>
+void launch_geo(lf_ctx* c, dim3 grid, int ntiles, int ntilesB, int nblkB, hipStream_t s, const lf::SrcArrays& sa,
+                const lf::NodeArrays& na, int B, int nchA, int nchB) {
     using namespace lf;
-    if (g.st == GEO_BIG.st)
-        hipLaunchKernelGGL((lf_main<VARIANT, GEO_BIG.st, GEO_BIG.tw, GEO_BIG.twb>), grid, dim3(BLOCK), 0, s, c->kc,
-                           sa, na, c->d_wrec, c->d_wmode, B, ntiles, ntilesB, nblkB, c->d_partA, nchA, c->d_partB, nchB);
-    else
-        hipLaunchKernelGGL((lf_main<VARIANT, GEO_SMALL.st, GEO_SMALL.tw, GEO_SMALL.twb>), grid, dim3(BLOCK), 0, s,
-                           c->kc, sa, na, c->d_wrec, c->d_wmode, B, ntiles, ntilesB, nblkB, c->d_partA, nchA,
-                           c->d_partB, nchB);
+    hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb>), grid, dim3(BLOCK), 0, s, c->kc, sa,
+                       na, c->d_wrec, c->d_wmode, B, ntiles, ntilesB, nblkB, c->d_partA, nchA, c->d_partB, nchB);
+}
+
+template <int VARIANT>
+void launch_main(lf_ctx* c, int gi, dim3 grid, int ntiles, int ntilesB, int nblkB, hipStream_t s,
+                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
+    switch (gi) {
+        case 0: launch_geo<VARIANT, 0>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 1: launch_geo<VARIANT, 1>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 2: launch_geo<VARIANT, 2>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 3: launch_geo<VARIANT, 3>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 4: launch_geo<VARIANT, 4>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+        default: launch_geo<VARIANT, 5>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB);
+    }
 }
 
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
             hipStream_t s) {
     using namespace lf;
-    const Geo geo = pick_geometry(c, B);
+    const int gi = pick_geometry(c, B);
+    const Geo geo = GEOS[gi];
     ChunkTable* ct = nullptr;
     int rc = get_chunks(c, geo.st * BLOCK, &ct);
     if (rc != LF_OK) return rc;
@@ -228,9 +238,9 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         const int nblkB = nchB * ntilesB;
         dim3 grid((unsigned)(nblkB + nchA * ntiles));     // 1-D: B workgroups first, then A (chunk, tile) per XCD
         switch (c->kc.variant) {
-            case LF_FREE: launch_main<LF_FREE>(c, geo, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, geo, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-            default: launch_main<LF_ZEVOL>(c, geo, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB);
+            case LF_FREE: launch_main<LF_FREE>(c, gi, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
+            default: launch_main<LF_ZEVOL>(c, gi, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB);
         }
     }
     {
@@ -572,12 +582,12 @@ int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
 
 int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return LF_ERR_ARG;
-    if (std::strcmp(key, "src_chunk") == 0) {
-        if (value != 0 && value != GEO_BIG.st * lf::BLOCK && value != GEO_SMALL.st * lf::BLOCK) {
-            c->err = "src_chunk must be 0 (auto), 512 or 2048";
+    if (std::strcmp(key, "geometry") == 0) {
+        if (value < -1 || value >= NGEO) {
+            c->err = "geometry must be -1 (auto) or an index below " + std::to_string(NGEO);
             return LF_ERR_ARG;
         }
-        c->opt_src_chunk = value;
+        c->opt_geometry = value;
         return LF_OK;
     }
     c->err = std::string("unknown option ") + key;
