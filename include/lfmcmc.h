@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 1
+#define LF_ABI_VERSION 2
 #define LF_MAX_FIELDS 8
 
 /* model variants = the three log-posterior callables of the reference */
@@ -127,6 +127,30 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * key "geometry": index of the launch geometry (sources per lane x walkers per workgroup),
  * -1 = chosen from N and B. */
 int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
+
+/*
+ * Device-resident ensemble sampler: the Goodman & Weare stretch move in its parallel form (two fixed
+ * half-ensembles, as emcee 2.x - the API the reference calls - implements it), with theta, lnprob
+ * and the chain kept in HBM.  Replaces
+ *     sampler = emcee.EnsembleSampler(nwalkers, ndim, lnprob); sampler.run_mcmc(pos, nsteps)
+ *     sampler.chain, sampler.lnprobability, sampler.acceptance_fraction      lumfuncmcmc.py:489-513
+ * One step = 2 x (propose+prepare, main, finalize+accept) = 6 launches, no host round trip.
+ * Random numbers are Philox4x32-10 keyed by `seed`: the chain is a pure function of (seed, start).
+ */
+typedef struct lf_sampler lf_sampler;
+
+/* `a` is the stretch scale (emcee default 2.0); capacity_steps sizes the on-device chain. */
+lf_sampler *lf_sampler_create(lf_ctx *ctx, int nwalkers, double a, uint64_t seed, int64_t capacity_steps);
+void lf_sampler_destroy(lf_sampler *s);
+/* pos: host [nwalkers][ndim].  lnprob0: host [nwalkers] or NULL (then evaluated here).  Resets the chain. */
+int lf_sampler_start(lf_sampler *s, const double *pos, const double *lnprob0);
+/* Enqueue nsteps full ensemble steps on hip_stream (NULL = the context's stream).  Asynchronous. */
+int lf_sampler_run(lf_sampler *s, int64_t nsteps, void *hip_stream);
+/* Synchronise and copy out; any pointer may be NULL.  chain: [nwalkers][steps][ndim] (emcee's
+ * sampler.chain layout), chain_lnprob: [nwalkers][steps], naccepted: [nwalkers], pos / lnprob: current state. */
+int lf_sampler_read(lf_sampler *s, double *chain, double *chain_lnprob, int64_t *naccepted, double *pos, double *lnprob);
+/* Steps recorded so far. */
+int64_t lf_sampler_steps(const lf_sampler *s);
 
 /* Last error message of this context (or of lf_create when ctx == NULL).  Never NULL. */
 const char *lf_last_error(const lf_ctx *ctx);

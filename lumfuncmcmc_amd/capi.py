@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblfmcmc.so")
 
-LF_ABI_VERSION = 1
+LF_ABI_VERSION = 2
 LF_MAX_FIELDS = 8
 LF_FREE, LF_FIXCOMP, LF_ZEVOL = 0, 1, 2
 VARIANTS = {"free": LF_FREE, "fixcomp": LF_FIXCOMP, "zevol": LF_ZEVOL}
@@ -41,7 +41,8 @@ class LfDesc(ctypes.Structure):
 
 EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_batch",
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
-           "lf_set_option", "lf_last_error")
+           "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
+           "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps")
 
 _lib = None
 
@@ -90,6 +91,18 @@ def load():
     lib.lf_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]
     lib.lf_last_error.restype = ctypes.c_char_p
     lib.lf_last_error.argtypes = [ctypes.c_void_p]
+    lib.lf_sampler_create.restype = ctypes.c_void_p
+    lib.lf_sampler_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_uint64, ctypes.c_int64]
+    lib.lf_sampler_destroy.restype = None
+    lib.lf_sampler_destroy.argtypes = [ctypes.c_void_p]
+    lib.lf_sampler_start.restype = ctypes.c_int
+    lib.lf_sampler_start.argtypes = [ctypes.c_void_p, _c_double_p, _c_double_p]
+    lib.lf_sampler_run.restype = ctypes.c_int
+    lib.lf_sampler_run.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.lf_sampler_read.restype = ctypes.c_int
+    lib.lf_sampler_read.argtypes = [ctypes.c_void_p, _c_double_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p]
+    lib.lf_sampler_steps.restype = ctypes.c_int64
+    lib.lf_sampler_steps.argtypes = [ctypes.c_void_p]
     v = lib.lf_abi_version()
     if v != LF_ABI_VERSION:
         raise RuntimeError("liblfmcmc.so ABI %d != binding ABI %d: rebuild the library" % (v, LF_ABI_VERSION))

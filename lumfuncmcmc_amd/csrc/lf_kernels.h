@@ -76,8 +76,13 @@ __device__ inline void quad_coef(double y1, double y2, double y3, double z1, dou
 
 // a z^2 + b z + c with the reference's roundings (lumfuncmcmc_z.py:65-66): with close pivots the
 // three terms cancel by two or three digits, so an FMA-contracted form drifts by ~1e-13 relative.
+// (HIP's __dmul_rn / __dadd_rn are plain * and + and may be contracted: the pragma is what holds.)
 __device__ __forceinline__ double quad_nofma(double a, double b, double c, double z, double z2) {
-    return __dadd_rn(__dadd_rn(__dmul_rn(a, z2), __dmul_rn(b, z)), c);
+#pragma clang fp contract(off)
+    const double t2 = a * z2;
+    const double t1 = b * z;
+    const double s = t2 + t1;
+    return s + c;
 }
 
 __device__ inline void quad_range(double a, double b, double c, double lo, double hi, double& mn, double& mx) {
@@ -92,6 +97,78 @@ __device__ inline void quad_range(double a, double b, double c, double lo, doubl
             mx = fmax(mx, vv);
         }
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// device-resident ensemble sampler (Goodman & Weare stretch move, the parallel form with two fixed
+// half-ensembles that emcee 2.x - the API the reference calls, lumfuncmcmc.py:489-491 - uses).
+// One half-step = propose (inside lf_prepare) -> lf_main -> accept (inside lf_finalize): theta never
+// leaves HBM and the host only enqueues.  Random numbers: Philox4x32-10, counter = (step, half,
+// walker, stream), key = seed, so a chain is a pure function of (seed, start) - tests replay it on
+// the host with the same generator.
+// ----------------------------------------------------------------------------------------------
+struct StepArgs {
+    int enabled;                 // 0: plain lnprob call (theta rows given)
+    int half, halfW, ndim;
+    unsigned long long step, seed;
+    double a;                    // stretch scale (2.0)
+    const double* pos;           // [W][ndim] current positions
+    double* prop;                // [halfW][ndim] proposals of the active half
+    double* zz;                  // [halfW] stretch factors
+};
+struct AcceptArgs {
+    int enabled;
+    int half, halfW, ndim;
+    unsigned long long step, seed;
+    long long t, cap;            // chain slot of this step, chain capacity (steps)
+    double* pos;                 // [W][ndim]
+    double* lnp;                 // [W]
+    const double* prop;          // [halfW][ndim]
+    const double* zz;            // [halfW]
+    long long* nacc;             // [W]
+    double* chain;               // [W][cap][ndim]
+    double* chain_lnp;           // [W][cap]
+};
+
+__device__ __forceinline__ void philox4x32(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                                           unsigned int k0, unsigned int k1, unsigned int (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// 53-bit uniform in [0, 1) from two words
+__device__ __forceinline__ double u53(unsigned int hi, unsigned int lo) {
+    return (double)((((unsigned long long)hi << 32) | lo) >> 11) * 1.1102230246251565e-16;
+}
+// z = ((a - 1) u + 1)^2 / a and y = x_j - (x_j - x_k) z, each operation rounded on its own (no FMA
+// contraction) so that a host replay with the same random numbers gives the same bits
+__device__ __forceinline__ double stretch_z(double a, double u) {
+#pragma clang fp contract(off)
+    const double t = (a - 1.0) * u;
+    const double g = t + 1.0;
+    const double g2 = g * g;
+    return g2 / a;
+}
+__device__ __forceinline__ double stretch_point(double xj, double xk, double z) {
+#pragma clang fp contract(off)
+    const double d = xj - xk;
+    const double dz = d * z;
+    return xj - dz;
+}
+__device__ __forceinline__ void sampler_draw(unsigned long long step, int half, int w, int stream,
+                                             unsigned long long seed, unsigned int (&r)[4]) {
+    philox4x32((unsigned int)step, (unsigned int)(step >> 32) ^ ((unsigned int)half << 31), (unsigned int)w,
+               (unsigned int)stream, (unsigned int)seed, (unsigned int)(seed >> 32), r);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -115,15 +192,35 @@ __device__ __forceinline__ int group8_or(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void lf_prepare(KConst kc, const double* __restrict__ theta, int B,
+__global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const double* __restrict__ theta, int B,
                                                  double* __restrict__ wrec, int* __restrict__ wstat,
                                                  int* __restrict__ wmode, double* __restrict__ wbase) {
+    __shared__ double sth[8][16];
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int wq = gt >> 3, f = gt & 7;
+    const int wq = gt >> 3, f = gt & 7, grp = threadIdx.x >> 3;
     const bool live = wq < B;
     const int w = live ? wq : B - 1;                 // idle groups replay the last walker, write nothing
     const bool has_f = f < kc.nf;
-    const double* th = theta + (size_t)w * kc.ndim;
+    // theta row of this walker -> LDS: either the given row, or the stretch-move proposal
+    //   y = x_j - (x_j - x_k) z,   z = ((a - 1) u + 1)^2 / a,   j uniform in the other half
+    if (sp.enabled) {
+        unsigned int rr[4];
+        sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
+        const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
+        const int j = (1 - sp.half) * sp.halfW + (int)(((unsigned long long)rr[2] * (unsigned long long)sp.halfW) >> 32);
+        const int k = sp.half * sp.halfW + w;
+        for (int i = f; i < sp.ndim; i += 8) {
+            const double xj = sp.pos[(size_t)j * sp.ndim + i], xk = sp.pos[(size_t)k * sp.ndim + i];
+            const double y = stretch_point(xj, xk, z);
+            sth[grp][i] = y;
+            if (live) sp.prop[(size_t)w * sp.ndim + i] = y;
+        }
+        if (live && f == 0) sp.zz[w] = z;
+    } else {
+        for (int i = f; i < kc.ndim; i += 8) sth[grp][i] = theta[(size_t)w * kc.ndim + i];
+    }
+    __syncthreads();
+    const double* th = sth[grp];
     double* r = wrec + (size_t)w * REC;
     const double SAFE = -700.0;
     bool ok = true;
@@ -491,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
 __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,
                                                   const double* __restrict__ partB, int nchB, int strideB,
                                                   const int* __restrict__ wstat,
-                                                  const double* __restrict__ wbase, int B,
+                                                  const double* __restrict__ wbase, int B, AcceptArgs ap,
                                                   double* __restrict__ out, double* __restrict__ outA,
                                                   double* __restrict__ outB) {
     const int w = blockIdx.x;
@@ -524,6 +621,30 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
         if (out) out[w] = r;
         if (outA) outA[w] = ok ? a : __builtin_nan("");
         if (outB) outB[w] = ok ? b : __builtin_nan("");
+        a = r;                                   // lane 0 keeps the new lnprob for the accept step
+    }
+    if (ap.enabled) {
+        // accept / reject walker k = half*halfW + w and record it in the chain (emcee keeps the state
+        // after the full step; a walker only changes in its own half-step)
+        const int k = ap.half * ap.halfW + w;
+        const double newlp = __shfl(a, 0, 64);
+        const double oldlp = ap.lnp[k];
+        unsigned int rr[4];
+        sampler_draw(ap.step, ap.half, w, 1, ap.seed, rr);
+        const double lnq = (ap.ndim - 1.0) * log(ap.zz[w]) + newlp - oldlp;
+        const bool acc = (log(u53(rr[0], rr[1])) < lnq) && (newlp > -__builtin_huge_val());
+        if (lane < ap.ndim) {
+            const double v = acc ? ap.prop[(size_t)w * ap.ndim + lane] : ap.pos[(size_t)k * ap.ndim + lane];
+            if (acc) ap.pos[(size_t)k * ap.ndim + lane] = v;
+            ap.chain[((size_t)k * ap.cap + ap.t) * ap.ndim + lane] = v;
+        }
+        if (lane == 0) {
+            if (acc) {
+                ap.lnp[k] = newlp;
+                ap.nacc[k] += 1;
+            }
+            ap.chain_lnp[(size_t)k * ap.cap + ap.t] = acc ? newlp : oldlp;
+        }
     }
 }
 

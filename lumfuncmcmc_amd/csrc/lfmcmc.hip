@@ -208,8 +208,12 @@ void launch_main(lf_ctx* c, int gi, dim3 grid, int ntiles, int ntilesB, int nblk
 }
 
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
-            hipStream_t s) {
+            hipStream_t s, const lf::StepArgs* step = nullptr, const lf::AcceptArgs* accept = nullptr) {
     using namespace lf;
+    StepArgs sp{};
+    AcceptArgs ap{};
+    if (step) sp = *step;
+    if (accept) ap = *accept;
     const int gi = pick_geometry(c, B);
     const Geo geo = GEOS[gi];
     ChunkTable* ct = nullptr;
@@ -226,7 +230,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
 
     {
         Prof p(c, s, 0);
-        hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, d_theta, B, c->d_wrec,
+        hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
                            c->d_wstat, c->d_wmode, c->d_wbase);
     }
     SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, ct->d_start, ct->d_len, ct->d_field};
@@ -246,7 +250,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           c->d_wstat, c->d_wbase, B, d_out, d_outA, d_outB);
+                           c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;
@@ -593,5 +597,128 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     c->err = std::string("unknown option ") + key;
     return LF_ERR_ARG;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * device-resident ensemble sampler
+ * ------------------------------------------------------------------------------------------- */
+struct lf_sampler {
+    lf_ctx* ctx = nullptr;
+    int W = 0, ndim = 0;
+    double a = 2.0;
+    uint64_t seed = 0, step = 0;
+    int64_t cap = 0, t = 0;
+    double *d_pos = nullptr, *d_lnp = nullptr, *d_prop = nullptr, *d_zz = nullptr, *d_newlp = nullptr;
+    double *d_chain = nullptr, *d_chain_lnp = nullptr;
+    long long* d_nacc = nullptr;
+    bool started = false;
+};
+
+lf_sampler* lf_sampler_create(lf_ctx* c, int nwalkers, double a, uint64_t seed, int64_t capacity_steps) {
+    if (!c) return nullptr;
+    if (nwalkers < 2 || (nwalkers & 1) || capacity_steps < 1 || !(a > 1.0)) {
+        c->err = "lf_sampler_create: nwalkers must be even and >= 2, a > 1, capacity_steps >= 1";
+        return nullptr;
+    }
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    lf_sampler* sm = new (std::nothrow) lf_sampler();
+    if (!sm) return nullptr;
+    sm->ctx = c;
+    sm->W = nwalkers;
+    sm->ndim = c->kc.ndim;
+    sm->a = a;
+    sm->seed = seed;
+    sm->cap = capacity_steps;
+    const size_t W = (size_t)nwalkers, nd = (size_t)sm->ndim, cap = (size_t)capacity_steps;
+    bool ok = hipMalloc((void**)&sm->d_pos, W * nd * 8) == hipSuccess && hipMalloc((void**)&sm->d_lnp, W * 8) == hipSuccess &&
+              hipMalloc((void**)&sm->d_prop, W * nd * 8) == hipSuccess && hipMalloc((void**)&sm->d_zz, W * 8) == hipSuccess &&
+              hipMalloc((void**)&sm->d_newlp, W * 8) == hipSuccess &&
+              hipMalloc((void**)&sm->d_chain, W * cap * nd * 8) == hipSuccess &&
+              hipMalloc((void**)&sm->d_chain_lnp, W * cap * 8) == hipSuccess &&
+              hipMalloc((void**)&sm->d_nacc, W * sizeof(long long)) == hipSuccess;
+    if (!ok) {
+        c->err = "lf_sampler_create: device allocation failed";
+        lf_sampler_destroy(sm);
+        return nullptr;
+    }
+    return sm;
+}
+
+void lf_sampler_destroy(lf_sampler* sm) {
+    if (!sm) return;
+    if (sm->ctx) {
+        hipSetDevice(sm->ctx->device);
+        hipDeviceSynchronize();
+    }
+    hipFree(sm->d_pos); hipFree(sm->d_lnp); hipFree(sm->d_prop); hipFree(sm->d_zz); hipFree(sm->d_newlp);
+    hipFree(sm->d_chain); hipFree(sm->d_chain_lnp); hipFree(sm->d_nacc);
+    delete sm;
+}
+
+int lf_sampler_start(lf_sampler* sm, const double* pos, const double* lnprob0) {
+    if (!sm || !pos) return LF_ERR_ARG;
+    lf_ctx* c = sm->ctx;
+    LF_HIP(c, hipSetDevice(c->device));
+    const size_t W = (size_t)sm->W, nd = (size_t)sm->ndim;
+    LF_HIP(c, hipMemcpy(sm->d_pos, pos, W * nd * 8, hipMemcpyHostToDevice));
+    LF_HIP(c, hipMemset(sm->d_nacc, 0, W * sizeof(long long)));
+    if (lnprob0) {
+        LF_HIP(c, hipMemcpy(sm->d_lnp, lnprob0, W * 8, hipMemcpyHostToDevice));
+    } else {
+        int rc = enqueue(c, sm->d_pos, sm->W, sm->d_lnp, nullptr, nullptr, c->stream);
+        if (rc != LF_OK) return rc;
+        LF_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    sm->step = 0;
+    sm->t = 0;
+    sm->started = true;
+    return LF_OK;
+}
+
+int lf_sampler_run(lf_sampler* sm, int64_t nsteps, void* hip_stream) {
+    if (!sm || nsteps < 0) return LF_ERR_ARG;
+    lf_ctx* c = sm->ctx;
+    if (!sm->started) {
+        c->err = "lf_sampler_run: call lf_sampler_start first";
+        return LF_ERR_ARG;
+    }
+    if (sm->t + nsteps > sm->cap) {
+        c->err = "lf_sampler_run: chain capacity exceeded";
+        return LF_ERR_ARG;
+    }
+    LF_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const int halfW = sm->W / 2;
+    for (int64_t it = 0; it < nsteps; ++it) {
+        for (int half = 0; half < 2; ++half) {
+            lf::StepArgs sp{1, half, halfW, sm->ndim, sm->step, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz};
+            lf::AcceptArgs ap{1, half, halfW, sm->ndim, sm->step, sm->seed, (long long)sm->t, (long long)sm->cap,
+                              sm->d_pos, sm->d_lnp, sm->d_prop, sm->d_zz, sm->d_nacc, sm->d_chain, sm->d_chain_lnp};
+            int rc = enqueue(c, nullptr, halfW, sm->d_newlp, nullptr, nullptr, s, &sp, &ap);
+            if (rc != LF_OK) return rc;
+        }
+        sm->step += 1;
+        sm->t += 1;
+    }
+    return LF_OK;
+}
+
+int lf_sampler_read(lf_sampler* sm, double* chain, double* chain_lnprob, int64_t* naccepted, double* pos, double* lnprob) {
+    if (!sm) return LF_ERR_ARG;
+    lf_ctx* c = sm->ctx;
+    LF_HIP(c, hipSetDevice(c->device));
+    LF_HIP(c, hipDeviceSynchronize());
+    const size_t W = (size_t)sm->W, nd = (size_t)sm->ndim, cap = (size_t)sm->cap, t = (size_t)sm->t;
+    // device chain is [W][cap][ndim]; the caller's is [W][t][ndim]
+    for (size_t k = 0; k < W && t > 0; ++k) {
+        if (chain) LF_HIP(c, hipMemcpy(chain + k * t * nd, sm->d_chain + k * cap * nd, t * nd * 8, hipMemcpyDeviceToHost));
+        if (chain_lnprob) LF_HIP(c, hipMemcpy(chain_lnprob + k * t, sm->d_chain_lnp + k * cap, t * 8, hipMemcpyDeviceToHost));
+    }
+    if (naccepted) LF_HIP(c, hipMemcpy(naccepted, sm->d_nacc, W * sizeof(long long), hipMemcpyDeviceToHost));
+    if (pos) LF_HIP(c, hipMemcpy(pos, sm->d_pos, W * nd * 8, hipMemcpyDeviceToHost));
+    if (lnprob) LF_HIP(c, hipMemcpy(lnprob, sm->d_lnp, W * 8, hipMemcpyDeviceToHost));
+    return LF_OK;
+}
+
+int64_t lf_sampler_steps(const lf_sampler* sm) { return sm ? sm->t : LF_ERR_ARG; }
 
 }  // extern "C"

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import hostsetup as hs
 from .capi import LFContext
-from .sampler import EnsembleSampler
+from .sampler import DeviceEnsembleSampler, EnsembleSampler
 
 TrueLumFunc = hs.true_lum_func       # module-level names the reference exports (lumfuncmcmc.py:25)
 schechter_z = hs.schechter_z         # lumfuncmcmc_z.py:45
@@ -184,8 +184,14 @@ class _Base(object):
         pos = self.get_init_walker_values()
         ndim = pos.shape[1]
         start = time.time()
-        sampler = EnsembleSampler(self.nwalkers, ndim, getattr(self, self._lnprob_name()), vectorize=True)
-        sampler.run_mcmc(pos, self.nsteps, rstate0=np.random.get_state())
+        if self.lnprob_fn is None and getattr(self, "device_sampler", True):
+            # single GPU: the whole stretch move runs on the device (theta never leaves HBM)
+            sampler = DeviceEnsembleSampler(self.context(), self.nwalkers, seed=int(np.random.randint(0, 2 ** 31 - 1)),
+                                            capacity=self.nsteps)
+            sampler.run_mcmc(pos, self.nsteps)
+        else:
+            sampler = EnsembleSampler(self.nwalkers, ndim, getattr(self, self._lnprob_name()), vectorize=True)
+            sampler.run_mcmc(pos, self.nsteps, rstate0=np.random.get_state())
         elapsed = time.time() - start
         self.log.info("Total time taken: %0.2f s" % elapsed)
         self.log.info("Time taken per step per walker: %0.2f ms" % (elapsed / (self.nsteps) * 1000. / self.nwalkers))

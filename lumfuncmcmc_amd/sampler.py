@@ -108,3 +108,84 @@ class EnsembleSampler(object):
     @property
     def acor(self):
         return self.get_autocorr_time()
+
+
+class DeviceEnsembleSampler(object):
+    """The same read-back surface, with the whole stretch move on the GPU (lf_sampler_* of
+    include/lfmcmc.h): positions, lnprob and the chain stay in HBM, a step is six kernel launches
+    and no host round trip.  Parallel stretch move with two fixed half-ensembles (emcee 2.x form);
+    Philox4x32-10 random numbers keyed by `seed`, so (seed, start) determines the chain
+    (tests/test_gpu_sampler.py replays it on the host)."""
+
+    def __init__(self, ctx, nwalkers, a=2.0, seed=0, capacity=1000):
+        import ctypes
+        if nwalkers < 2 * ctx.ndim or nwalkers % 2:
+            raise ValueError("nwalkers must be even and at least 2*ndim (got %d for ndim %d)" % (nwalkers, ctx.ndim))
+        self._ct = ctypes
+        self.ctx, self.nwalkers, self.ndim, self.a, self.seed = ctx, int(nwalkers), ctx.ndim, float(a), int(seed)
+        self.capacity = int(capacity)
+        h = ctx._lib.lf_sampler_create(ctx._h, self.nwalkers, self.a, ctypes.c_uint64(self.seed), self.capacity)
+        if not h:
+            raise RuntimeError("lf_sampler_create failed: %s" % ctx._lib.lf_last_error(ctx._h).decode())
+        self._h = ctypes.c_void_p(h)
+        self._started = False
+
+    def _p(self, a):
+        return a.ctypes.data_as(self._ct.POINTER(self._ct.c_double)) if a is not None else None
+
+    def run_mcmc(self, pos, nsteps, rstate0=None, lnprob0=None):
+        """pos=None continues from the current state.  Enqueues and returns after the last step has
+        been read back (use `enqueue` + `sync` to overlap with host work)."""
+        self.enqueue(pos, nsteps, lnprob0)
+        return self.sync()
+
+    def enqueue(self, pos, nsteps, lnprob0=None):
+        lib = self.ctx._lib
+        if pos is not None or not self._started:
+            p = np.ascontiguousarray(pos, dtype=np.float64)
+            if p.shape != (self.nwalkers, self.ndim):
+                raise ValueError("pos must be (nwalkers, ndim)")
+            l0 = None if lnprob0 is None else np.ascontiguousarray(lnprob0, dtype=np.float64)
+            self.ctx._check(lib.lf_sampler_start(self._h, self._p(p), self._p(l0)))
+            self._started = True
+        self.ctx._check(lib.lf_sampler_run(self._h, int(nsteps), None))
+
+    def sync(self):
+        lib = self.ctx._lib
+        t = int(lib.lf_sampler_steps(self._h))
+        W, nd = self.nwalkers, self.ndim
+        self.chain = np.empty((W, t, nd))
+        self.lnprobability = np.empty((W, t))
+        self.naccepted = np.empty(W, dtype=np.int64)
+        pos, lp = np.empty((W, nd)), np.empty(W)
+        self.ctx._check(lib.lf_sampler_read(self._h, self._p(self.chain), self._p(self.lnprobability),
+                                            self.naccepted.ctypes.data_as(self._ct.POINTER(self._ct.c_int64)),
+                                            self._p(pos), self._p(lp)))
+        self.iterations = t
+        return pos, lp, None
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(self.iterations, 1)
+
+    @property
+    def flatchain(self):
+        return self.chain.reshape(-1, self.ndim)
+
+    def get_autocorr_time(self, c=5.0):
+        return np.array([integrated_time(self.chain[:, :, d].T, c=c) for d in range(self.ndim)])
+
+    @property
+    def acor(self):
+        return self.get_autocorr_time()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self.ctx._lib.lf_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
