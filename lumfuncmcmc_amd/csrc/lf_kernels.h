@@ -309,10 +309,13 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
             }
         }
     }
-    if (live && has_f) wmode[(size_t)w * MAXF + f] = m;
     base = group8_sum(base);
     const int bad = group8_or(ok ? 0 : 1);
     neginf = group8_or(neginf);
+    // a walker outside the prior, or already known to be -inf, gets lnprob = -inf whatever its sums are:
+    // it must not drag its tile onto the careful path (stretch-move proposals leave the box often)
+    if (bad || neginf) m = MODE_FAST;
+    if (live && has_f) wmode[(size_t)w * MAXF + f] = m;
     if (live && f == 0) {
         wbase[w] = base;
         wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0);

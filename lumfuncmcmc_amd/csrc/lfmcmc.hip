@@ -708,10 +708,12 @@ int lf_sampler_read(lf_sampler* sm, double* chain, double* chain_lnprob, int64_t
     LF_HIP(c, hipSetDevice(c->device));
     LF_HIP(c, hipDeviceSynchronize());
     const size_t W = (size_t)sm->W, nd = (size_t)sm->ndim, cap = (size_t)sm->cap, t = (size_t)sm->t;
-    // device chain is [W][cap][ndim]; the caller's is [W][t][ndim]
-    for (size_t k = 0; k < W && t > 0; ++k) {
-        if (chain) LF_HIP(c, hipMemcpy(chain + k * t * nd, sm->d_chain + k * cap * nd, t * nd * 8, hipMemcpyDeviceToHost));
-        if (chain_lnprob) LF_HIP(c, hipMemcpy(chain_lnprob + k * t, sm->d_chain_lnp + k * cap, t * 8, hipMemcpyDeviceToHost));
+    // device chain is [W][cap][ndim]; the caller's is [W][t][ndim]: one strided copy each
+    if (t > 0) {
+        if (chain)
+            LF_HIP(c, hipMemcpy2D(chain, t * nd * 8, sm->d_chain, cap * nd * 8, t * nd * 8, W, hipMemcpyDeviceToHost));
+        if (chain_lnprob)
+            LF_HIP(c, hipMemcpy2D(chain_lnprob, t * 8, sm->d_chain_lnp, cap * 8, t * 8, W, hipMemcpyDeviceToHost));
     }
     if (naccepted) LF_HIP(c, hipMemcpy(naccepted, sm->d_nacc, W * sizeof(long long), hipMemcpyDeviceToHost));
     if (pos) LF_HIP(c, hipMemcpy(pos, sm->d_pos, W * nd * 8, hipMemcpyDeviceToHost));
