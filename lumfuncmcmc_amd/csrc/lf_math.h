@@ -3,9 +3,9 @@
 // Everything on the path is fp64 VALU work: there is no contraction, so no MFMA.  The terms are
 // dominated by exp / log / rsqrt / reciprocal, so the kernels carry their own versions, sized
 // for this path (known argument ranges, ~1 ulp, no special-case branches):
-//   fexp_t     table-driven: 64-entry 2^(j/64) table in LDS, magic-number rounding (no cvt),
-//              degree-5 polynomial on |r| <= ln2/128, ldexp
-//   flog_half  table-driven: 128 x {1/c, log c} in LDS, degree-6 log1p on |r| < 2^-8
+//   fexp_t     table-driven: 256-entry 2^(j/256) table in LDS, magic-number rounding (no cvt),
+//              degree-4 polynomial on |r| <= ln2/512, ldexp
+//   flog_half  table-driven: 256 x {1/c, log c} in LDS, degree-5 log1p on |r| < 2^-9
 //   frsqrt     v_rsq_f64 seed (2^-24 measured on gfx950) + one cubic step
 //   frcp       v_rcp_f64 seed (2^-24) + one cubic Newton step
 // The "careful" path (rare walkers that may underflow, see lf_kernels.h) uses the ROCm device
@@ -36,41 +36,39 @@ __device__ __forceinline__ double ddiv(double a, double b) { return a / b; }
 // ---- fast versions
 // LDS image of the tables of lf_tables.h
 struct MathTables {
-    double2 logt[128];   // {1/c_j, log c_j}
-    double expt[64];     // 2^(j/64)
+    double2 logt[256];   // {1/c_j, log c_j}
+    double expt[256];    // 2^(j/256)
 };
 
-// e^x, table-driven: 64 x / ln2 = 64 n + j + (64 / ln2) r, |r| <= ln2/128, e^x = 2^n 2^(j/64) e^r.
-// Valid for |x| < 2^24 (results below 2^-1075 come out as 0 through ldexp); no clamps, NaN in -> NaN out.
+// e^x, table-driven: 256 x / ln2 = 256 n + j + (256 / ln2) r, |r| <= ln2/512, e^x = 2^n 2^(j/256) e^r.
+// Valid for |x| < 2^22 (results below 2^-1075 come out as 0 through ldexp); no clamps, NaN in -> NaN out.
 __device__ __forceinline__ double fexp_t(double x, const MathTables* __restrict__ mt) {
     const double MAGIC = 6755399441055744.0;                     // 1.5 * 2^52
-    const double t = fma(x, 92.332482616893656877, MAGIC);       // 64 / ln2; low word of t = round(64 x / ln2)
+    const double t = fma(x, 369.32993046757463, MAGIC);          // 256 / ln2; low word of t = round(256 x / ln2)
     const double kd = t - MAGIC;
-    double r = fma(kd, -1.08304246932675596326e-02, x);          // ln2_hi / 64 (kd * hi exact)
-    r = fma(kd, -2.98158582698529328128e-12, r);                 // ln2_lo / 64
+    double r = fma(kd, -0.00270760617331689, x);          // ln2_hi / 256 (kd * hi exact)
+    r = fma(kd, -7.453964567463233e-13, r);                 // ln2_lo / 256
     const int k = __double2loint(t);
-    const double T = mt->expt[k & 63];
-    double q = fma(r, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
-    q = fma(q, r, 1.66666666666666666667e-01);
+    const double T = mt->expt[k & 255];
+    double q = fma(r, 4.16666666666666666667e-02, 1.66666666666666666667e-01);
     q = fma(q, r, 0.5);
-    const double p = fma(r * r, q, r);                           // e^r - 1
-    return ldexp(fma(T, p, T), k >> 6);
+    const double p = fma(r * r, q, r);                           // e^r - 1, |r|^5/120 < 4e-17
+    return ldexp(fma(T, p, T), k >> 8);
 }
 
 // e^(-u) for the completeness decay 1 - e^(-u), u >= 0.  One-constant reduction: the error of
-// ln2/64 as a double adds u * 1.1e-16 relative to e^(-u), i.e. at most 4e-17 absolute to 1 - e^(-u).
+// ln2/256 as a double adds u * 1.1e-16 relative to e^(-u), i.e. at most 4e-17 absolute to 1 - e^(-u).
 __device__ __forceinline__ double fexp_neg(double u, const MathTables* __restrict__ mt) {
     const double MAGIC = 6755399441055744.0;
-    const double t = fma(u, -92.332482616893656877, MAGIC);
+    const double t = fma(u, -369.32993046757463, MAGIC);
     const double kd = t - MAGIC;
-    const double r = fma(kd, -1.08304246962491454596e-02, -u);   // ln2 / 64
+    const double r = fma(kd, -0.0027076061740622863, -u);   // ln2 / 256
     const int k = __double2loint(t);
-    const double T = mt->expt[k & 63];
-    double q = fma(r, 8.33333333333333333333e-03, 4.16666666666666666667e-02);
-    q = fma(q, r, 1.66666666666666666667e-01);
+    const double T = mt->expt[k & 255];
+    double q = fma(r, 4.16666666666666666667e-02, 1.66666666666666666667e-01);
     q = fma(q, r, 0.5);
     const double p = fma(r * r, q, r);
-    return ldexp(fma(T, p, T), k >> 6);
+    return ldexp(fma(T, p, T), k >> 8);
 }
 
 // the same with the argument clamped to [-750, 709] (grid kernels: arguments are not pre-screened)
@@ -82,12 +80,11 @@ __device__ __forceinline__ double fexp_c(double x, const MathTables* __restrict_
 __device__ __forceinline__ double flog_half(double w, const MathTables* __restrict__ mt) {
     const int hi = __double2hiint(w), lo = __double2loint(w);
     const int e = ((hi >> 20) & 0x7ff) - 1024;                       // exponent of w/2
-    const int j = (hi >> 13) & 0x7f;
+    const int j = (hi >> 12) & 0xff;
     const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);   // mantissa in [1, 2)
     const double2 t = mt->logt[j];
     const double r = fma(m, t.x, -1.0);
-    double p = fma(r, -1.0 / 6.0, 0.2);
-    p = fma(p, r, -0.25);
+    double p = fma(r, 0.2, -0.25);                                   // |r| < 2^-9: r^6/6 < 1e-17
     p = fma(p, r, 1.0 / 3.0);
     p = fma(p, r, -0.5);
     const double r2 = r * r;
@@ -112,8 +109,10 @@ __device__ __forceinline__ double frcp(double d) {
 
 // copy the tables to LDS (call with all threads, then __syncthreads())
 __device__ __forceinline__ void load_tables(MathTables* mt) {
-    for (int i = threadIdx.x; i < 128; i += blockDim.x) mt->logt[i] = make_double2(LOG_TABLE[2 * i], LOG_TABLE[2 * i + 1]);
-    for (int i = threadIdx.x; i < 64; i += blockDim.x) mt->expt[i] = EXP_TABLE[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        mt->logt[i] = make_double2(LOG_TABLE[2 * i], LOG_TABLE[2 * i + 1]);
+        mt->expt[i] = EXP_TABLE[i];
+    }
 }
 
 // 64-lane wavefront sum (no masks on CDNA: every lane takes part).

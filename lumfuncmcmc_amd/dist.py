@@ -32,24 +32,37 @@ class ShardedLnProb(object):
         self.local_eval, self.ndim, self.device, self.group = local_eval, ndim, device, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._buffers = {}
+        try:
+            import inspect
+            self._eval_takes_out = len(inspect.signature(local_eval).parameters) >= 2
+        except (TypeError, ValueError):
+            self._eval_takes_out = False
 
     def evaluate_tensor(self, theta):
-        """theta: (B, ndim) float64 tensor on self.device -> (B,) tensor on self.device."""
+        """theta: (B, ndim) float64 tensor on self.device -> (B,) tensor on self.device.  The gather
+        buffer is kept per B and the local slice is written straight into it (in-place all-gather:
+        no staging copy, no allocation per call)."""
         torch, dist = self.torch, self.dist
         B = theta.shape[0]
         if self.world == 1:
             return self.local_eval(theta)
         bounds, per = slice_bounds(B, self.world)
         lo, hi = bounds[self.rank]
-        mine = torch.full((per,), float("-inf"), dtype=torch.float64, device=self.device)
+        full = self._buffers.get(B)
+        if full is None:
+            full = torch.full((per * self.world,), float("-inf"), dtype=torch.float64, device=self.device)
+            self._buffers[B] = full
+        mine = full[self.rank * per:(self.rank + 1) * per]
         if hi > lo:
-            mine[:hi - lo] = self.local_eval(theta[lo:hi].contiguous())
-        full = torch.empty(per * self.world, dtype=torch.float64, device=self.device)
+            out = mine[:hi - lo]
+            res = self.local_eval(theta[lo:hi].contiguous(), out) if self._eval_takes_out else self.local_eval(theta[lo:hi].contiguous())
+            if res.data_ptr() != out.data_ptr():
+                out.copy_(res)
         dist.all_gather_into_tensor(full, mine, group=self.group)
         if per * self.world == B:
             return full
-        keep = torch.cat([full[r * per:r * per + (b - a)] for r, (a, b) in enumerate(bounds)])
-        return keep
+        return torch.cat([full[r * per:r * per + (b - a)] for r, (a, b) in enumerate(bounds)])
 
     def __call__(self, theta):
         t = self.torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64)).to(self.device)
