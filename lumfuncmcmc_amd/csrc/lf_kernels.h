@@ -471,33 +471,39 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             red[w * BLOCK + tid] = acc;
         }
     } else {
-        // careful path: device-library math, per-term underflow checks, -inf poisoning
+        // careful path (rare): device-library math, per-term underflow checks, -inf poisoning.  Items are
+        // re-read from memory inside a rolled loop so that this path adds no register pressure to the
+        // fast one.
 #pragma unroll 1
         for (int w = 0; w < nw; ++w) {
             const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
             double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < ST; ++k) {   // static indices: the item registers must not go to scratch
+#pragma unroll 1
+            for (int k = 0; k < ST; ++k) {
+                const int i = k * BLOCK + tid;
+                if (i >= n) break;
+                const size_t g = (size_t)s0 + i;
+                const double clum = sa.lum[g], ca1 = sa.a1[g], cpp = sa.P[g];
                 double term;
                 if (VARIANT == LF_FREE) {
                     const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
                                    r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
-                    term = term_free_careful(wf, lum[k], wgt[k] != 0.0 ? a1[k] : 0.0, pp[k], wgt[k] != 0.0 ? uu[k] : 1.0);
+                    term = term_free_careful(wf, clum, ca1, cpp, sa.U[g]);
                 } else if (VARIANT == LF_FIXCOMP) {
-                    const double v = pp[k] * r[R_Q];
-                    const double lnT = fma(r[R_C1], lum[k] - r[R_LSTAR], r[R_C0]) - v;
-                    term = lnT + a1[k];
+                    const double v = cpp * r[R_Q];
+                    const double lnT = fma(r[R_C1], clum - r[R_LSTAR], r[R_C0]) - v;
+                    term = lnT + ca1;
                     const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
                     term = bad ? NEG_INF : 0.0;             // the value itself is in wbase
                 } else {
                     const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
                     double v;
-                    const double lnT = lnT_zevol<false>(wz, lum[k], a1[k], uu[k], v, &tab);
-                    term = lnT + pp[k];
+                    const double lnT = lnT_zevol<false>(wz, clum, ca1, sa.U[g], v, &tab);
+                    term = lnT + cpp;
                     const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
                     term = bad ? NEG_INF : lnT;
                 }
-                acc += wgt[k] != 0.0 ? term : 0.0;
+                acc += term;
             }
             red[w * BLOCK + tid] = acc;
         }
