@@ -14,6 +14,8 @@ import time
 import numpy as np
 
 from . import hostsetup as hs
+from . import veff
+from .cosmology import cosmo as _cosmo
 from .capi import LFContext
 from .sampler import DeviceEnsembleSampler, EnsembleSampler
 
@@ -348,8 +350,7 @@ class LumFuncMCMC(_Base):
         return vals
 
     def set_median_fit(self, rndsamples=200, lnprobcut=7.5):
-        """Median model LF over random posterior draws (lumfuncmcmc.py:527-567), without the
-        1/Veff estimator (VeffLF is outside this build's scope: SURVEY.md section 8f row 3)."""
+        """Median model LF over random posterior draws, then the 1/Veff estimate (lumfuncmcmc.py:527-567)."""
         nsamples = self._select_samples(lnprobcut, keep_lnprob=True)
         Flims, alphas = np.zeros((rndsamples, self.nfields)), np.zeros(rndsamples)
         lf = []
@@ -363,11 +364,20 @@ class LumFuncMCMC(_Base):
         self._veff_or_skip()
 
     def VeffLF(self):
-        raise NotImplementedError("VeffLF (1/Veff estimator with bootstrap errors, lumfuncmcmc.py:515-525) "
-                                  "is a post-fit diagnostic outside the scope of this build")
+        """1/Veff weights per source and the binned LF with bootstrap errors (lumfuncmcmc.py:515-525)."""
+        self.getFlim()
+        sum_Omega = sum(self.Omega_0)
+        if self.min_comp_frac <= 0.001:
+            zmaxval = self.zmax
+        else:
+            root = self.rootsf.ev(self.Flims_arr, self.alpha)
+            zmaxval = np.minimum(self.zmax, veff.max_redshift(10 ** self.lum, root, _cosmo))
+        self.phifunc = veff.lumfunc_weights(self.flux, self.dVdzf, sum_Omega, self.zmin, zmaxval,
+                                            1.0e-17 * self.Flims_arr, self.alpha, self.fcmin)
+        self.Lavg, self.lfbinorig, self.var = veff.boot_err_log(self.lum, self.phifunc, self.nboot, self.nbins)
 
     def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
-        raise NotImplementedError("triangle_plot needs corner/matplotlib and VeffLF; outside the scope of this build")
+        raise NotImplementedError("triangle_plot needs corner/matplotlib; plotting is outside the scope of this build (use set_median_fit)")
 
 
 class LumFuncMCMCz(_Base):
@@ -486,8 +496,15 @@ class LumFuncMCMCz(_Base):
         self._veff_or_skip()
 
     def VeffLF(self):
-        raise NotImplementedError("VeffLF (lumfuncmcmc_z.py:470-478) is a post-fit diagnostic outside "
-                                  "the scope of this build")
+        """lumfuncmcmc_z.py:470-478."""
+        sum_Omega = sum(self.Omega_0)
+        if self.min_comp_frac <= 0.001:
+            zmaxval = self.zmax
+        else:
+            zmaxval = np.minimum(self.zmax, veff.max_redshift(10 ** self.lum, self.roots_arr, _cosmo))
+        self.phifunc = veff.lumfunc_weights(self.flux, self.dVdzf, sum_Omega, self.zmin, zmaxval,
+                                            1.0e-17 * self.Flims_arr, self.alpha, self.fcmin)
+        self.Lavg, self.lfbinorig, self.var = veff.boot_err_log(self.lum, self.phifunc, self.nboot, self.nbins)
 
     def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
-        raise NotImplementedError("triangle_plot needs corner/matplotlib and VeffLF; outside the scope of this build")
+        raise NotImplementedError("triangle_plot needs corner/matplotlib; plotting is outside the scope of this build (use set_median_fit)")

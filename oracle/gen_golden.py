@@ -265,12 +265,43 @@ def main():
                     field_ind=cat["field_ind"], diff_rand=True)
 
     manifest = {}
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only:
+        with open(os.path.join(OUT, "MANIFEST.json")) as f:
+            manifest = json.load(f)
 
     def save(name, d):
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **d)
         manifest[name] = {"bytes": os.path.getsize(path), "keys": sorted(d.keys())}
         print("wrote", path, os.path.getsize(path))
+
+    # ---- 1/Veff estimator (LumFuncMCMC.VeffLF, lumfuncmcmc.py:515-525): per-source weights from
+    #      V.lumfunc (one scipy.quad each) and the bootstrap of V.getBootErrLog with a seeded global state
+    def veff_case(name, n, seed, mcf, nboot, nbins, rseed):
+        cat = S.catalogue(n, seed=seed)
+        kw = ctor_kwargs(cat, False, False, mcf)
+        kw.update(nboot=nboot, nbins=nbins)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with np.errstate(all="ignore"):
+                o = R.LumFuncMCMC(S.split_fields(cat["z"], cat["field_ind"]), **kw)
+                np.random.seed(rseed)
+                import io, contextlib
+                with contextlib.redirect_stdout(io.StringIO()):
+                    o.VeffLF()
+        save(name, dict(z=o.z, lum=o.lum, lum_e=o.lum_e, field_ind=np.asarray(o.field_ind, dtype=np.int64),
+                        flux=o.flux, phifunc=o.phifunc, Lavg=o.Lavg, lfbinorig=o.lfbinorig, var=o.var,
+                        min_comp_frac=mcf, nboot=nboot, nbins=nbins, rseed=rseed, seed=seed))
+
+    if only in (None, "veff"):
+        veff_case("veff_n1000", 1000, 0, 0.0, 100, 50, 12345)
+        veff_case("veff_n200_mcf50", 200, 7, 0.5, 20, 10, 54321)
+    if only:
+        with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print("done (only %s)" % only)
+        return
 
     # ---- FREE variant (lnprob, S=101): N = 50, 1000, 10000, with and without fixed alpha
     for (n, seed, fsa, nrows, tables) in ((50, 0, False, 24, True), (1000, 0, False, 40, True),
