@@ -297,6 +297,39 @@ def main():
     if only in (None, "veff"):
         veff_case("veff_n1000", 1000, 0, 0.0, 100, 50, 12345)
         veff_case("veff_n200_mcf50", 200, 7, 0.5, 20, 10, 54321)
+    # ---- table formats: a catalogue written by astropy, what the driver's read_input_file
+    #      (run_lumfuncmcmc.py:165-228) makes of it, and astropy's fixed_width_two_line output
+    if only in (None, "tableio"):
+        import io, contextlib
+        from astropy.table import Table
+        with contextlib.redirect_stdout(io.StringIO()):
+            import run_lumfuncmcmc as DRV
+        rng = np.random.default_rng(77)
+        n = 60
+        fnames = np.array(["AEGIS", "COSMOS", "GOODSN", "GOODSS", "UDS"])
+        fld = fnames[rng.integers(0, 5, n)]
+        cat = Table([fld, np.arange(n), rng.uniform(S.ZLO, S.ZHI, n), rng.uniform(0.3, 30.0, n),
+                     rng.uniform(0.1, 1.0, n)], names=["Field", "ID", "z", "OIII_flux", "OIII_flux_e"])
+        cpath = os.path.join(OUT, "catalogue_n60.dat")
+        cat.write(cpath, format="ascii", overwrite=True)
+        for mcf, tag in ((0.0, "mcf0"), (0.5, "mcf50")):
+            args = types.SimpleNamespace(filename=cpath, min_comp_frac=mcf, Flim=list(S.FLIM), alpha=S.ALPHA_C,
+                                         fcmin=S.FCMIN, line_name="OIII")
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                z, flux, flux_e, lum, lum_e, field_names, field_ind = DRV.read_input_file(args, dust_fn=None)[:7]
+            save("readinput_%s" % tag, dict(z=np.concatenate(z), flux=np.concatenate(flux), flux_e=np.concatenate(flux_e),
+                                            field_names=np.array([str(x) for x in field_names]),
+                                            field_ind=np.asarray(field_ind, dtype=np.int64), min_comp_frac=mcf))
+        T = Table([rng.uniform(41, 43, 6), np.full(6, 0.05), rng.uniform(1e-4, 1e-2, 6)],
+                  names=["Luminosity", "Luminosity_Err", "MedianLF"])
+        T.write(os.path.join(OUT, "fwtl_plain.dat"), overwrite=True, format="ascii.fixed_width_two_line")
+        np.save(os.path.join(OUT, "fwtl_plain_cols.npy"), np.array([T[c] for c in T.colnames]))
+        names = ["Line", r"$\log L_*$_05", r"$\log L_*$_50"]
+        T2 = Table(names=names, dtype=["S10", "f8", "f8"])
+        T2.add_row(["OIII", 42.123456, 42.5])
+        T2.write(os.path.join(OUT, "fwtl_formats.dat"), format="ascii.fixed_width_two_line", overwrite=True,
+                 formats={"Line": "%s", names[1]: "%0.3f", names[2]: "%0.3f"})
     if only:
         with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
