@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--geometry", type=int, default=-1)
+    ap.add_argument("--walker-tile", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
@@ -120,6 +121,8 @@ def main():
     ctx = model.context()
     if args.geometry >= 0:
         ctx.set_option("geometry", args.geometry)
+    if args.walker_tile:
+        ctx.set_option("walker_tile", args.walker_tile)
     ndim = ctx.ndim
     from lumfuncmcmc_amd import synth
     # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled

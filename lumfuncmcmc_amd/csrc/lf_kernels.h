@@ -30,13 +30,13 @@
 namespace lf {
 
 constexpr int BLOCK = 256;   // 4 waves
-constexpr int REC = 24;      // doubles per walker record
+constexpr int REC = 32;      // doubles per walker record
 constexpr int MAXF = 8;
 enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2 };
 enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2 };
 
 // walker record, FREE / FIXCOMP
-enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4, R_LF = 8, R_V = 16 };
+enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4, R_LF = 8, R_V = 16, R_CA = 24 };   // R_CA = -alpha_C lF
 // walker record, ZEVOL
 enum { Z_AL = 0, Z_BL = 1, Z_CL = 2, Z_AP = 3, Z_BP = 4, Z_CP = 5, Z_C1 = 6 };
 
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
                 if (live) {
                     r[R_LF + f] = lF;
                     r[R_V + f] = V;
+                    r[R_CA + f] = -alphaC * lF;
                 }
             }
             if (kc.nsrc[f] > 0) {
@@ -336,7 +337,7 @@ __device__ __forceinline__ double ln_fc_fast(double num, const MathTables* __res
 }
 
 struct WFree {   // wave-uniform walker constants of one (walker, field)
-    double Lstar, c0f, c1, Q, alphaC, lF, V, lnom0;
+    double Lstar, c0f, c1, Q, alphaC, lF, V, lnom0, cA;
 };
 
 // completeness part of the term, ln(fc) / (1 - e^(-f/f_tau)); the Schechter part and ln Omega_0 are
@@ -346,7 +347,7 @@ __device__ __forceinline__ double term_free_fast(const WFree& w, double logf, do
     // ln(fc) / d with fc = (1 + num / sqrt(s)) / 2, s = 1 + num^2, d = 1 - e^(-U V)  (VmaxLumFunc.py:118-127, :141)
     // needs 1/sqrt(s) and 1/d: ONE v_rsq_f64 seed serves both, Z = rsqrt(s d^2) = 1 / (sqrt(s) d), then
     // 1/sqrt(s) = Z d and 1/d = Z^2 s d  (a quarter-rate seed costs four FMA slots)
-    const double num = w.alphaC * (logf - w.lF);
+    const double num = fma(w.alphaC, logf, w.cA);            // alpha_C (logf - lF), one FMA
     const double s = fma(num, num, 1.0);
     const double d = 1.0 - fexp_neg(U * w.V, tab);
     const double sd = s * d;
@@ -412,8 +413,8 @@ struct SrcArrays {
 
 template <int VARIANT, int ST, int TW>
 __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& sa, const double* __restrict__ wrec,
-                                            const int* __restrict__ wmode, int B, int ntiles, int id, int nblk,
-                                            double* __restrict__ partial, int pstride,
+                                            const int* __restrict__ wmode, int B, int ntiles, int tw, int id,
+                                            int nblk, double* __restrict__ partial, int pstride,
                                             const MathTables& tab, double* __restrict__ red) {
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its
     // own L2.  Renumber so that the ntiles workgroups that read the SAME chunk of the catalogue are
@@ -428,8 +429,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
         tile = wg - c * ntiles;
     }
     const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
-    const int w0 = tile * TW;
-    const int nw = min(TW, B - w0);
+    const int w0 = tile * tw;                       // tw <= TW walkers per tile (TW sizes the LDS buffer)
+    const int nw = min(tw, B - w0);
 
     // items -> registers (lanes past the end replay the chunk's first source with weight 0)
     double lum[ST], a1[ST], pp[ST], uu[ST], wgt[ST];
@@ -455,13 +456,27 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
 
     const double NEG_INF = -__builtin_huge_val();
     if (mode == MODE_FAST) {
+        // walker constants of the NEXT walker are fetched (scalar loads) while the current one computes
+        double nxA = 0.0, nxC = 0.0, nxV = 0.0;
+        if (VARIANT == LF_FREE) {
+            const double* __restrict__ r0 = wrec + (size_t)w0 * REC;
+            nxA = r0[R_ALPHAC];
+            nxC = r0[R_CA + fld];
+            nxV = r0[R_V + fld];
+        }
 #pragma unroll 1
         for (int w = 0; w < nw; ++w) {
             const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
             double acc = 0.0;
             if (VARIANT == LF_FREE) {
-                const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
-                               r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
+                WFree wf{};
+                wf.alphaC = nxA;
+                wf.cA = nxC;
+                wf.V = nxV;
+                const double* __restrict__ rn = wrec + (size_t)(w0 + min(w + 1, nw - 1)) * REC;
+                nxA = rn[R_ALPHAC];
+                nxC = rn[R_CA + fld];
+                nxV = rn[R_V + fld];
 #pragma unroll
                 for (int k = 0; k < ST; ++k) acc += term_free_fast(wf, a1[k], uu[k], &tab);
             } else if (VARIANT == LF_FIXCOMP) {
@@ -494,7 +509,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 double term;
                 if (VARIANT == LF_FREE) {
                     const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
-                                   r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld]};
+                                   r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld], 0.0};
                     term = term_free_careful(wf, clum, ca1, cpp, sa.U[g]);
                 } else if (VARIANT == LF_FIXCOMP) {
                     const double v = cpp * r[R_Q];
@@ -535,12 +550,12 @@ struct NodeArrays {
 
 template <int VARIANT, int TW>
 __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays& na, const double* __restrict__ wrec,
-                                             int B, int ntiles, int id, double* __restrict__ partial, int pstride,
-                                             const MathTables& tab, double* __restrict__ red) {
+                                             int B, int ntiles, int tw, int id, double* __restrict__ partial,
+                                             int pstride, const MathTables& tab, double* __restrict__ red) {
     const int tid = threadIdx.x;
     const int c = id / ntiles, tile = id - c * ntiles;
-    const int w0 = tile * TW;
-    const int nw = min(TW, B - w0);
+    const int w0 = tile * tw;
+    const int nw = min(tw, B - w0);
     const int gi = c * BLOCK + tid;
     const bool valid = gi < na.nnodes;
     const int g = valid ? gi : 0;
@@ -582,7 +597,7 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
 template <int VARIANT, int ST, int TW, int TWB>
 __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeArrays na,
                                                  const double* __restrict__ wrec, const int* __restrict__ wmode,
-                                                 int B, int ntiles, int ntilesB, int nblkB,
+                                                 int B, int ntiles, int tw, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
                                                  double* __restrict__ partB, int strideB) {
     __shared__ MathTables tab;
@@ -591,10 +606,10 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
     __syncthreads();
     const int id = blockIdx.x;
     if (id < nblkB)
-        gridsum_body<VARIANT, TWB>(kc, na, wrec, B, ntilesB, id, partB, strideB, tab, red);
+        gridsum_body<VARIANT, TWB>(kc, na, wrec, B, ntilesB, twb, id, partB, strideB, tab, red);
     else
-        srcsum_body<VARIANT, ST, TW>(kc, sa, wrec, wmode, B, ntiles, id - nblkB, (int)gridDim.x - nblkB, partA,
-                                     strideA, tab, red);
+        srcsum_body<VARIANT, ST, TW>(kc, sa, wrec, wmode, B, ntiles, tw, id - nblkB, (int)gridDim.x - nblkB,
+                                     partA, strideA, tab, red);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -46,6 +46,7 @@ struct lf_ctx {
     double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr;
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
+    int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     // workspace
     int cap_B = 0;                      // padded walker capacity
     size_t cap_partA = 0, cap_partB = 0;
@@ -187,23 +188,23 @@ struct Prof {
 
 // enqueue the three launches of one batched evaluation on `s`: prepare -> main (A and B) -> finalize
 template <int VARIANT, int GI>
-void launch_geo(lf_ctx* c, dim3 grid, int ntiles, int ntilesB, int nblkB, hipStream_t s, const lf::SrcArrays& sa,
-                const lf::NodeArrays& na, int B, int nchA, int nchB) {
+void launch_geo(lf_ctx* c, dim3 grid, int ntiles, int tw, int ntilesB, int twb, int nblkB, hipStream_t s,
+                const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
     using namespace lf;
     hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                       na, c->d_wrec, c->d_wmode, B, ntiles, ntilesB, nblkB, c->d_partA, nchA, c->d_partB, nchB);
+                       na, c->d_wrec, c->d_wmode, B, ntiles, tw, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB);
 }
 
 template <int VARIANT>
-void launch_main(lf_ctx* c, int gi, dim3 grid, int ntiles, int ntilesB, int nblkB, hipStream_t s,
+void launch_main(lf_ctx* c, int gi, dim3 grid, int ntiles, int tw, int ntilesB, int twb, int nblkB, hipStream_t s,
                  const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
     switch (gi) {
-        case 0: launch_geo<VARIANT, 0>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 1: launch_geo<VARIANT, 1>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 2: launch_geo<VARIANT, 2>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 3: launch_geo<VARIANT, 3>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 4: launch_geo<VARIANT, 4>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-        default: launch_geo<VARIANT, 5>(c, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB);
+        case 0: launch_geo<VARIANT, 0>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 1: launch_geo<VARIANT, 1>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 2: launch_geo<VARIANT, 2>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 3: launch_geo<VARIANT, 3>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 4: launch_geo<VARIANT, 4>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        default: launch_geo<VARIANT, 5>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
     }
 }
 
@@ -237,14 +238,19 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->nnodes};
     {
         Prof p(c, s, 1);
-        const int ntiles = (B + geo.tw - 1) / geo.tw;
-        const int ntilesB = (B + geo.twb - 1) / geo.twb;
+        int tw = geo.tw, twb = geo.twb;
+        if (c->opt_walker_tile > 0) {
+            tw = (int)std::min<int64_t>(c->opt_walker_tile, geo.tw);
+            twb = (int)std::min<int64_t>(c->opt_walker_tile, geo.twb);
+        }
+        const int ntiles = (B + tw - 1) / tw;
+        const int ntilesB = (B + twb - 1) / twb;
         const int nblkB = nchB * ntilesB;
         dim3 grid((unsigned)(nblkB + nchA * ntiles));     // 1-D: B workgroups first, then A (chunk, tile) per XCD
         switch (c->kc.variant) {
-            case LF_FREE: launch_main<LF_FREE>(c, gi, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB); break;
-            default: launch_main<LF_ZEVOL>(c, gi, grid, ntiles, ntilesB, nblkB, s, sa, na, B, nchA, nchB);
+            case LF_FREE: launch_main<LF_FREE>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+            default: launch_main<LF_ZEVOL>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
         }
     }
     {
@@ -592,6 +598,14 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             return LF_ERR_ARG;
         }
         c->opt_geometry = value;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "walker_tile") == 0) {
+        if (value < 0 || value > 64) {
+            c->err = "walker_tile must be 0 (auto) .. 64";
+            return LF_ERR_ARG;
+        }
+        c->opt_walker_tile = value;
         return LF_OK;
     }
     c->err = std::string("unknown option ") + key;
