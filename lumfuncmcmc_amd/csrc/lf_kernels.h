@@ -62,6 +62,7 @@ struct KConst {
     double slc[MAXF];         // sum (lum_i - 42)
     double sp[MAXF];          // sum 10^(lum_i - 42)
     double som[MAXF];         // FIXCOMP/ZEVOL: sum ln(Om_arr_i)
+    double sz[MAXF], sz2[MAXF];   // ZEVOL: sum z_i, sum z_i^2  (L*(z), phi*(z) enter the log-terms linearly)
 };
 
 // getQuadCoef, lumfuncmcmc_z.py:40-42, with the reference's operation order and no FMA contraction
@@ -252,7 +253,12 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
             const double vb = pow(10.0, tmax);
             const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
             m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
-            base = kc.som[f];                      // sum_i ln Om_arr_i does not depend on theta
+            // closed-form part: sum_i [ln Om_i + ln ln10 + ln10 phi*(z_i) + c1 (lum_i - L*(z_i))]; only
+            // -10^(lum_i - L*(z_i)) is left per source
+            const double n = (double)kc.nsrc[f];
+            const double sph = aP * kc.sz2[f] + bP * kc.sz[f] + n * cP;
+            const double sls = aL * kc.sz2[f] + bL * kc.sz[f] + n * (cL - LF_LREF);
+            base = kc.som[f] + n * LF_LNLN10 + LF_LN10 * sph + c1 * (kc.slc[f] - sls);
         }
     } else {
         const double Lstar = th[0], phistar = th[1];
@@ -458,15 +464,19 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     if (mode == MODE_FAST) {
         // walker constants of the NEXT walker are fetched (scalar loads) while the current one computes
         double nxA = 0.0, nxC = 0.0, nxV = 0.0;
+        WZ nz{};
         if (VARIANT == LF_FREE) {
             const double* __restrict__ r0 = wrec + (size_t)w0 * REC;
             nxA = r0[R_ALPHAC];
             nxC = r0[R_CA + fld];
             nxV = r0[R_V + fld];
         }
+        if (VARIANT == LF_ZEVOL) {
+            const double* __restrict__ r0 = wrec + (size_t)w0 * REC;
+            nz = WZ{r0[Z_AL], r0[Z_BL], r0[Z_CL], r0[Z_AP], r0[Z_BP], r0[Z_CP], r0[Z_C1]};
+        }
 #pragma unroll 1
         for (int w = 0; w < nw; ++w) {
-            const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
             double acc = 0.0;
             if (VARIANT == LF_FREE) {
                 WFree wf{};
@@ -482,12 +492,14 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             } else if (VARIANT == LF_FIXCOMP) {
                 // nothing left per source: piece A is the closed form in wbase
             } else {
-                const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
+                const WZ wz = nz;
+                const double* __restrict__ rn = wrec + (size_t)(w0 + min(w + 1, nw - 1)) * REC;
+                nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
 #pragma unroll
                 for (int k = 0; k < ST; ++k) {
-                    double v;
-                    const double lnT = lnT_zevol<true>(wz, lum[k], a1[k], uu[k], v, &tab);
-                    acc = fma(lnT, wgt[k], acc);            // sum ln Om_arr_i is in wbase
+                    const double Ls = quad_nofma(wz.aL, wz.bL, wz.cL, a1[k], uu[k]);      // L*(z_i), lumfuncmcmc_z.py:66
+                    const double v = fexp_c(LF_LN10 * (lum[k] - Ls), &tab);             // 10^(lum_i - L*(z_i))
+                    acc = fma(-v, wgt[k], acc);             // everything else of the term is in wbase
                 }
             }
             red[w * BLOCK + tid] = acc;
@@ -523,7 +535,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                     const double lnT = lnT_zevol<false>(wz, clum, ca1, sa.U[g], v, &tab);
                     term = lnT + cpp;
                     const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
-                    term = bad ? NEG_INF : lnT;
+                    term = bad ? NEG_INF : -v;              // the rest of the term is in wbase
                 }
                 acc += term;
             }

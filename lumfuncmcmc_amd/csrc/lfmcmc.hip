@@ -344,7 +344,7 @@ int build(lf_ctx* c, const lf_desc* d) {
     // per-field extremes for the mode classification in lf_prepare
     for (int f = 0; f < MAXF; ++f) {
         kc.nsrc[f] = 0;
-        kc.pmax[f] = kc.lum_min[f] = kc.lum_max[f] = kc.a_min[f] = kc.u_min[f] = kc.u_max[f] = kc.z_lo[f] = kc.z_hi[f] = kc.slc[f] = kc.sp[f] = kc.som[f] = 0.0;
+        kc.pmax[f] = kc.lum_min[f] = kc.lum_max[f] = kc.a_min[f] = kc.u_min[f] = kc.u_max[f] = kc.z_lo[f] = kc.z_hi[f] = kc.slc[f] = kc.sp[f] = kc.som[f] = kc.sz[f] = kc.sz2[f] = 0.0;
     }
     for (int f = 0; f < nf; ++f) {
         const int64_t lo = d->field_ind[f], hi = d->field_ind[f + 1];
@@ -352,13 +352,17 @@ int build(lf_ctx* c, const lf_desc* d) {
         if (hi <= lo) continue;
         double pmax = -HUGE_VAL, lmin = HUGE_VAL, lmax = -HUGE_VAL, amin = HUGE_VAL, amax = -HUGE_VAL, zlo = HUGE_VAL, zhi = -HUGE_VAL;
         bool nan = false;
-        long double slc = 0.0L, sp = 0.0L, som = 0.0L;
+        long double slc = 0.0L, sp = 0.0L, som = 0.0L, sz = 0.0L, sz2 = 0.0L;
         for (int64_t i = lo; i < hi; ++i) {
             const double lum = d->lum[i];
             slc += (long double)(lum - LF_LREF);
             if (d->variant != LF_ZEVOL) sp += (long double)P[i];
             if (d->variant == LF_FIXCOMP) som += (long double)a1[i];
-            if (d->variant == LF_ZEVOL) som += (long double)P[i];
+            if (d->variant == LF_ZEVOL) {
+                som += (long double)P[i];
+                sz += (long double)d->z[i];
+                sz2 += (long double)U[i];             // the rounded z_i^2 the kernels use
+            }
             lmin = std::fmin(lmin, lum);
             lmax = std::fmax(lmax, lum);
             nan = nan || std::isnan(lum);
@@ -385,6 +389,8 @@ int build(lf_ctx* c, const lf_desc* d) {
         kc.slc[f] = (double)slc;
         kc.sp[f] = (double)sp;
         kc.som[f] = (double)som;
+        kc.sz[f] = (double)sz;
+        kc.sz2[f] = (double)sz2;
     }
     int rc;
     if ((rc = upload(c, &c->d_lum, d->lum, (size_t)N)) != LF_OK) return rc;
