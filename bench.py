@@ -31,14 +31,14 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
 # the compiler's assembly (profiles/isa_mix.py -> profiles/r01_isa_mix.txt): FMA = 2, any other fp64
 # VALU instruction = 1.  (The survey's nominal weights - exp/log = 40 flops - would put the same
 # run at ~100 % of peak; DESIGN.md section 4 explains why that figure is not used.)
-FLOPS_PER_TERM = {"free": 61.0, "zevol": 38.0, "fixcomp": 0.0}
+FLOPS_PER_TERM = {"free": 54.0, "zevol": 27.0, "fixcomp": 0.0}
 # issue cycles one wave spends per term (fp64 VALU 4, v_rcp/v_rsq_f64 16, 32-bit VALU 2.5; measured
 # rates in profiles/r01_ubench.txt), for the issue-utilisation figure
-CYCLES_PER_TERM = {"free": 203.0, "zevol": 108.0, "fixcomp": 0.0}
-# bytes the per-source kernel streams per source: lum, logf and the two hoisted powers (free);
-# lum, z, ln Om, z^2 (zevol).  SURVEY.md section 8d counts 16 B (lum, logf): the other 16 B buy two exp
-# per (source, walker tile) - HBM is not the binding roof.
-BYTES_PER_SOURCE = {"free": 32, "fixcomp": 24, "zevol": 32}
+CYCLES_PER_TERM = {"free": 174.0, "zevol": 81.0, "fixcomp": 0.0}
+# bytes the per-source loop streams per source and launch: logf_i and U_i = 10^(logf_i + 17) (free: the
+# Schechter part is closed-form per walker, so lum_i is not read); lum, z, z^2 (zevol); nothing (fixcomp).
+# SURVEY.md section 8d also counts 16 B for the free variant.
+BYTES_PER_SOURCE = {"free": 16, "fixcomp": 0, "zevol": 24}
 
 
 def build_model(variant, nsrc, walkers, device):
