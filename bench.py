@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--geometry", type=int, default=-1)
     ap.add_argument("--walker-tile", type=int, default=0)
+    ap.add_argument("--default-stream", action="store_true", help="launch on the legacy default stream instead of a side stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
@@ -141,6 +142,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the launches go on a non-blocking side stream (what a host application would use): the legacy
+    # default stream serialises against every other stream of the process
+    side = None if args.default_stream else torch.cuda.Stream(device=dev)
+    if side is not None:
+        torch.cuda.set_stream(side)
     for i in range(args.warmup):
         out = step(i)
     fence()

@@ -151,6 +151,15 @@ int lf_sampler_run(lf_sampler *s, int64_t nsteps, void *hip_stream);
 int lf_sampler_read(lf_sampler *s, double *chain, double *chain_lnprob, int64_t *naccepted, double *pos, double *lnprob);
 /* Steps recorded so far. */
 int64_t lf_sampler_steps(const lf_sampler *s);
+/* Walker-sharded form of one half-step (multi-GPU: one process per GPU, every rank holds the whole
+ * ensemble).  half_eval proposes for the whole half (half = 0 or 1) and evaluates lnprob of the
+ * proposals lo..hi-1 (indices within the half) into d_newlp[lo..hi-1] (device); the caller all-gathers
+ * d_newlp over the ranks (RCCL); half_accept then accepts/rejects the whole half and records the chain
+ * (after half 1 the step counter advances).  Both enqueue on hip_stream as given (NULL = the default
+ * stream, as in lf_lnprob_batch_device), so that the collective in between is stream-ordered with them.
+ * Same random numbers and arithmetic as lf_sampler_run: the chain is identical for any sharding. */
+int lf_sampler_half_eval(lf_sampler *s, int half, int lo, int hi, double *d_newlp, void *hip_stream);
+int lf_sampler_half_accept(lf_sampler *s, int half, const double *d_newlp, void *hip_stream);
 
 /* Last error message of this context (or of lf_create when ctx == NULL).  Never NULL. */
 const char *lf_last_error(const lf_ctx *ctx);

@@ -42,7 +42,8 @@ class LfDesc(ctypes.Structure):
 EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_batch",
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
-           "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps")
+           "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
+           "lf_sampler_half_accept")
 
 _lib = None
 
@@ -103,6 +104,10 @@ def load():
     lib.lf_sampler_read.argtypes = [ctypes.c_void_p, _c_double_p, _c_double_p, _c_int64_p, _c_double_p, _c_double_p]
     lib.lf_sampler_steps.restype = ctypes.c_int64
     lib.lf_sampler_steps.argtypes = [ctypes.c_void_p]
+    lib.lf_sampler_half_eval.restype = ctypes.c_int
+    lib.lf_sampler_half_eval.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.lf_sampler_half_accept.restype = ctypes.c_int
+    lib.lf_sampler_half_accept.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     v = lib.lf_abi_version()
     if v != LF_ABI_VERSION:
         raise RuntimeError("liblfmcmc.so ABI %d != binding ABI %d: rebuild the library" % (v, LF_ABI_VERSION))

@@ -23,7 +23,8 @@
 //     FAST    a lower bound of every factor is far above the underflow threshold (the normal case)
 //             -> branch-free terms with the tuned math of lf_math.h, no per-term checks
 //     SLOW    anything else -> per-term checks with the device-library math, -inf poisoning
-// The mode is uniform per workgroup (tile x field), so the choice costs one scalar branch.
+// The mode is per (walker, field) and wave-uniform inside the walker loop: one scalar branch per walker,
+// and a walker's result never depends on which other walkers share its tile.
 #pragma once
 #include "lf_math.h"
 
@@ -456,34 +457,34 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             uu[k] = 1.0e4;
         }
     }
-    int mode = MODE_FAST;
-    for (int w = 0; w < nw; ++w) mode = max(mode, wmode[(size_t)(w0 + w) * MAXF + fld]);
-    mode = __builtin_amdgcn_readfirstlane(mode);
-
     const double NEG_INF = -__builtin_huge_val();
-    if (mode == MODE_FAST) {
-        // walker constants of the NEXT walker are fetched (scalar loads) while the current one computes
-        double nxA = 0.0, nxC = 0.0, nxV = 0.0;
-        WZ nz{};
+    // walker constants (and the walker's mode) of the NEXT walker are fetched with scalar loads while the
+    // current one computes.  The mode branch is per walker and wave-uniform: a walker's sum never
+    // depends on which other walkers share its tile (lnprob is a function of its theta row alone).
+    double nxA = 0.0, nxC = 0.0, nxV = 0.0;
+    WZ nz{};
+    int nxm = wmode[(size_t)w0 * MAXF + fld];
+    {
+        const double* __restrict__ r0 = wrec + (size_t)w0 * REC;
         if (VARIANT == LF_FREE) {
-            const double* __restrict__ r0 = wrec + (size_t)w0 * REC;
             nxA = r0[R_ALPHAC];
             nxC = r0[R_CA + fld];
             nxV = r0[R_V + fld];
         }
-        if (VARIANT == LF_ZEVOL) {
-            const double* __restrict__ r0 = wrec + (size_t)w0 * REC;
-            nz = WZ{r0[Z_AL], r0[Z_BL], r0[Z_CL], r0[Z_AP], r0[Z_BP], r0[Z_CP], r0[Z_C1]};
-        }
+        if (VARIANT == LF_ZEVOL) nz = WZ{r0[Z_AL], r0[Z_BL], r0[Z_CL], r0[Z_AP], r0[Z_BP], r0[Z_CP], r0[Z_C1]};
+    }
 #pragma unroll 1
-        for (int w = 0; w < nw; ++w) {
-            double acc = 0.0;
+    for (int w = 0; w < nw; ++w) {
+        const int mode = __builtin_amdgcn_readfirstlane(nxm);
+        const double* __restrict__ rn = wrec + (size_t)(w0 + min(w + 1, nw - 1)) * REC;
+        nxm = wmode[(size_t)(w0 + min(w + 1, nw - 1)) * MAXF + fld];
+        double acc = 0.0;
+        if (mode != MODE_SLOW) {
             if (VARIANT == LF_FREE) {
                 WFree wf{};
                 wf.alphaC = nxA;
                 wf.cA = nxC;
                 wf.V = nxV;
-                const double* __restrict__ rn = wrec + (size_t)(w0 + min(w + 1, nw - 1)) * REC;
                 nxA = rn[R_ALPHAC];
                 nxC = rn[R_CA + fld];
                 nxV = rn[R_V + fld];
@@ -493,7 +494,6 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 // nothing left per source: piece A is the closed form in wbase
             } else {
                 const WZ wz = nz;
-                const double* __restrict__ rn = wrec + (size_t)(w0 + min(w + 1, nw - 1)) * REC;
                 nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
 #pragma unroll
                 for (int k = 0; k < ST; ++k) {
@@ -502,16 +502,17 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                     acc = fma(-v, wgt[k], acc);             // everything else of the term is in wbase
                 }
             }
-            red[w * BLOCK + tid] = acc;
-        }
-    } else {
-        // careful path (rare): device-library math, per-term underflow checks, -inf poisoning.  Items are
-        // re-read from memory inside a rolled loop so that this path adds no register pressure to the
-        // fast one.
-#pragma unroll 1
-        for (int w = 0; w < nw; ++w) {
+        } else {
+            // careful path (rare): device-library math, per-term underflow checks, -inf poisoning.  Items
+            // are re-read from memory inside a rolled loop so that this path adds no register pressure
+            // to the fast one.
             const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
-            double acc = 0.0;
+            if (VARIANT == LF_FREE) {
+                nxA = rn[R_ALPHAC];
+                nxC = rn[R_CA + fld];
+                nxV = rn[R_V + fld];
+            }
+            if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
 #pragma unroll 1
             for (int k = 0; k < ST; ++k) {
                 const int i = k * BLOCK + tid;
@@ -539,8 +540,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 }
                 acc += term;
             }
-            red[w * BLOCK + tid] = acc;
         }
+        red[w * BLOCK + tid] = acc;
     }
     __syncthreads();
     reduce_store(red, nw, partial, (size_t)pstride, w0, c);
@@ -624,6 +625,53 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
                                      partA, strideA, tab, red);
 }
 
+// accept / reject walker k = half*halfW + w with the new lnprob `newlp`, and record it in the chain
+// (emcee keeps the state after the full step; a walker only changes in its own half-step).  One wave
+// per walker; lanes < ndim move the coordinates.
+__device__ __forceinline__ void accept_walker(const AcceptArgs& ap, int w, double newlp, int lane) {
+    const int k = ap.half * ap.halfW + w;
+    const double oldlp = ap.lnp[k];
+    unsigned int rr[4];
+    sampler_draw(ap.step, ap.half, w, 1, ap.seed, rr);
+    const double lnq = (ap.ndim - 1.0) * log(ap.zz[w]) + newlp - oldlp;
+    const bool acc = (log(u53(rr[0], rr[1])) < lnq) && (newlp > -__builtin_huge_val());
+    if (lane < ap.ndim) {
+        const double v = acc ? ap.prop[(size_t)w * ap.ndim + lane] : ap.pos[(size_t)k * ap.ndim + lane];
+        if (acc) ap.pos[(size_t)k * ap.ndim + lane] = v;
+        ap.chain[((size_t)k * ap.cap + ap.t) * ap.ndim + lane] = v;
+    }
+    if (lane == 0) {
+        if (acc) {
+            ap.lnp[k] = newlp;
+            ap.nacc[k] += 1;
+        }
+        ap.chain_lnp[(size_t)k * ap.cap + ap.t] = acc ? newlp : oldlp;
+    }
+}
+
+// the two halves of a sampler half-step as separate launches, for the walker-sharded (multi-GPU)
+// sampler: every rank proposes for the whole half, evaluates its slice with the plain lnprob path,
+// all-gathers, and accepts for the whole half - same arithmetic as the fused path, same chain.
+__global__ __launch_bounds__(64) void lf_propose(StepArgs sp) {
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = gt >> 3, f = gt & 7;
+    if (w >= sp.halfW) return;
+    unsigned int rr[4];
+    sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
+    const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
+    const int j = (1 - sp.half) * sp.halfW + (int)(((unsigned long long)rr[2] * (unsigned long long)sp.halfW) >> 32);
+    const int k = sp.half * sp.halfW + w;
+    for (int i = f; i < sp.ndim; i += 8)
+        sp.prop[(size_t)w * sp.ndim + i] = stretch_point(sp.pos[(size_t)j * sp.ndim + i], sp.pos[(size_t)k * sp.ndim + i], z);
+    if (f == 0) sp.zz[w] = z;
+}
+
+__global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __restrict__ newlp) {
+    const int w = blockIdx.x;
+    if (w >= ap.halfW) return;
+    accept_walker(ap, w, newlp[w], threadIdx.x);
+}
+
 // ----------------------------------------------------------------------------------------------
 // finalize: one wave per walker; fixed-order sum of the partials; lnprob = lnprior + A - B.
 // lumfuncmcmc.py:378, :403-409.  Never NaN (emcee raises on NaN): NaN -> -inf.
@@ -666,29 +714,7 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
         if (outB) outB[w] = ok ? b : __builtin_nan("");
         a = r;                                   // lane 0 keeps the new lnprob for the accept step
     }
-    if (ap.enabled) {
-        // accept / reject walker k = half*halfW + w and record it in the chain (emcee keeps the state
-        // after the full step; a walker only changes in its own half-step)
-        const int k = ap.half * ap.halfW + w;
-        const double newlp = __shfl(a, 0, 64);
-        const double oldlp = ap.lnp[k];
-        unsigned int rr[4];
-        sampler_draw(ap.step, ap.half, w, 1, ap.seed, rr);
-        const double lnq = (ap.ndim - 1.0) * log(ap.zz[w]) + newlp - oldlp;
-        const bool acc = (log(u53(rr[0], rr[1])) < lnq) && (newlp > -__builtin_huge_val());
-        if (lane < ap.ndim) {
-            const double v = acc ? ap.prop[(size_t)w * ap.ndim + lane] : ap.pos[(size_t)k * ap.ndim + lane];
-            if (acc) ap.pos[(size_t)k * ap.ndim + lane] = v;
-            ap.chain[((size_t)k * ap.cap + ap.t) * ap.ndim + lane] = v;
-        }
-        if (lane == 0) {
-            if (acc) {
-                ap.lnp[k] = newlp;
-                ap.nacc[k] += 1;
-            }
-            ap.chain_lnp[(size_t)k * ap.cap + ap.t] = acc ? newlp : oldlp;
-        }
-    }
+    if (ap.enabled) accept_walker(ap, w, __shfl(a, 0, 64), lane);
 }
 
 }  // namespace lf

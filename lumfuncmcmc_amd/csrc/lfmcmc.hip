@@ -743,4 +743,43 @@ int lf_sampler_read(lf_sampler* sm, double* chain, double* chain_lnprob, int64_t
 
 int64_t lf_sampler_steps(const lf_sampler* sm) { return sm ? sm->t : LF_ERR_ARG; }
 
+int lf_sampler_half_eval(lf_sampler* sm, int half, int lo, int hi, double* d_newlp, void* hip_stream) {
+    if (!sm || !d_newlp || half < 0 || half > 1 || lo < 0 || hi < lo || hi > sm->W / 2) return LF_ERR_ARG;
+    lf_ctx* c = sm->ctx;
+    if (!sm->started || sm->t >= sm->cap) {
+        c->err = "lf_sampler_half_eval: not started, or chain capacity exceeded";
+        return LF_ERR_ARG;
+    }
+    LF_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)hip_stream;          // as given: NULL is the default stream (cf. lf_lnprob_batch_device)
+    const int halfW = sm->W / 2;
+    lf::StepArgs sp{1, half, halfW, sm->ndim, sm->step, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz};
+    hipLaunchKernelGGL(lf::lf_propose, dim3((halfW + 7) / 8), dim3(64), 0, s, sp);
+    LF_HIP(c, hipGetLastError());
+    if (hi > lo)
+        return enqueue(c, sm->d_prop + (size_t)lo * sm->ndim, hi - lo, d_newlp + lo, nullptr, nullptr, s);
+    return LF_OK;
+}
+
+int lf_sampler_half_accept(lf_sampler* sm, int half, const double* d_newlp, void* hip_stream) {
+    if (!sm || !d_newlp || half < 0 || half > 1) return LF_ERR_ARG;
+    lf_ctx* c = sm->ctx;
+    if (!sm->started || sm->t >= sm->cap) {
+        c->err = "lf_sampler_half_accept: not started, or chain capacity exceeded";
+        return LF_ERR_ARG;
+    }
+    LF_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)hip_stream;          // as given: NULL is the default stream (cf. lf_lnprob_batch_device)
+    const int halfW = sm->W / 2;
+    lf::AcceptArgs ap{1, half, halfW, sm->ndim, sm->step, sm->seed, (long long)sm->t, (long long)sm->cap,
+                      sm->d_pos, sm->d_lnp, sm->d_prop, sm->d_zz, sm->d_nacc, sm->d_chain, sm->d_chain_lnp};
+    hipLaunchKernelGGL(lf::lf_accept, dim3(halfW), dim3(64), 0, s, ap, d_newlp);
+    LF_HIP(c, hipGetLastError());
+    if (half == 1) {
+        sm->step += 1;
+        sm->t += 1;
+    }
+    return LF_OK;
+}
+
 }  // extern "C"

@@ -33,6 +33,9 @@ class ShardedLnProb(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._buffers = {}
+        # RCCL/NCCL gathers in place (the input is the rank's slice of the output); other backends
+        # (gloo in the CPU tests and one-GPU rehearsals) get a separate input buffer
+        self._inplace = dist.is_initialized() and dist.get_backend(group) == "nccl"
         try:
             import inspect
             self._eval_takes_out = len(inspect.signature(local_eval).parameters) >= 2
@@ -54,12 +57,19 @@ class ShardedLnProb(object):
             full = torch.full((per * self.world,), float("-inf"), dtype=torch.float64, device=self.device)
             self._buffers[B] = full
         mine = full[self.rank * per:(self.rank + 1) * per]
+        if not self._inplace:
+            mine = self._buffers.setdefault(("in", B), torch.full((per,), float("-inf"), dtype=torch.float64,
+                                                                  device=self.device))
         if hi > lo:
             out = mine[:hi - lo]
             res = self.local_eval(theta[lo:hi].contiguous(), out) if self._eval_takes_out else self.local_eval(theta[lo:hi].contiguous())
             if res.data_ptr() != out.data_ptr():
                 out.copy_(res)
+        if not self._inplace and self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()        # gloo (rehearsal) does not order with our launches
         dist.all_gather_into_tensor(full, mine, group=self.group)
+        if not self._inplace and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
         if per * self.world == B:
             return full
         return torch.cat([full[r * per:r * per + (b - a)] for r, (a, b) in enumerate(bounds)])

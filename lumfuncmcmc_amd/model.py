@@ -187,10 +187,27 @@ class _Base(object):
         ndim = pos.shape[1]
         start = time.time()
         if self.lnprob_fn is None and getattr(self, "device_sampler", True):
-            # single GPU: the whole stretch move runs on the device (theta never leaves HBM)
-            sampler = DeviceEnsembleSampler(self.context(), self.nwalkers, seed=int(np.random.randint(0, 2 ** 31 - 1)),
-                                            capacity=self.nsteps)
-            sampler.run_mcmc(pos, self.nsteps)
+            # the whole stretch move runs on the device (theta never leaves HBM).  With torch.distributed
+            # initialised (one process per GPU) the walkers of every half-step are sharded over the ranks
+            # and the per-walker lnprob is all-gathered (RCCL) before the accept step; start and seed come
+            # from rank 0 so that every rank carries the same ensemble.
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+            world = 1
+            try:
+                import torch.distributed as tdist
+                if tdist.is_available() and tdist.is_initialized():
+                    world = tdist.get_world_size()
+                    box = [pos, seed]
+                    tdist.broadcast_object_list(box, src=0)
+                    pos, seed = box
+            except ImportError:
+                pass
+            sampler = DeviceEnsembleSampler(self.context(), self.nwalkers, seed=seed, capacity=self.nsteps)
+            if world > 1:
+                sampler.enqueue_sharded(pos, self.nsteps)
+                sampler.sync()
+            else:
+                sampler.run_mcmc(pos, self.nsteps)
         else:
             sampler = EnsembleSampler(self.nwalkers, ndim, getattr(self, self._lnprob_name()), vectorize=True)
             sampler.run_mcmc(pos, self.nsteps, rstate0=np.random.get_state())

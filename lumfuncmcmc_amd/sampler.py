@@ -150,6 +150,48 @@ class DeviceEnsembleSampler(object):
             self._started = True
         self.ctx._check(lib.lf_sampler_run(self._h, int(nsteps), None))
 
+    def enqueue_sharded(self, pos, nsteps, group=None, lnprob0=None):
+        """The same chain with the walkers of every half-step sharded over the ranks of a
+        torch.distributed group (one process per GPU): propose everywhere, evaluate the local slice,
+        all-gather the slice's lnprob (RCCL, in stream order), accept everywhere."""
+        import torch
+        import torch.distributed as dist
+        from .dist import slice_bounds
+        lib, ct = self.ctx._lib, self._ct
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if pos is not None or not self._started:
+            p = np.ascontiguousarray(pos, dtype=np.float64)
+            l0 = None if lnprob0 is None else np.ascontiguousarray(lnprob0, dtype=np.float64)
+            self.ctx._check(lib.lf_sampler_start(self._h, self._p(p), self._p(l0)))
+            self._started = True
+        half = self.nwalkers // 2
+        bounds, per = slice_bounds(half, world)
+        lo, hi = bounds[rank]
+        dev = torch.device("cuda", self.ctx.device)
+        buf = torch.full((per * world,), float("-inf"), dtype=torch.float64, device=dev)
+        inplace = world > 1 and dist.get_backend(group) == "nccl"      # RCCL gathers in place
+        sep = None if (inplace or world == 1) else torch.full((per,), float("-inf"), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for _ in range(int(nsteps)):
+            for h in (0, 1):
+                # slices are padded to `per` rows per rank: the gather buffer is [world][per]
+                mine = buf[rank * per:(rank + 1) * per] if sep is None else sep
+                self.ctx._check(lib.lf_sampler_half_eval(self._h, h, lo, hi, ct.c_void_p(mine.data_ptr() - lo * 8),
+                                                         ct.c_void_p(stream)))
+                if world > 1:
+                    if not inplace:
+                        torch.cuda.current_stream(dev).synchronize()    # gloo (rehearsal) does not order with our launches
+                    dist.all_gather_into_tensor(buf, mine, group=group)
+                    if not inplace:
+                        torch.cuda.synchronize(dev)                     # ... nor its result with the next launch
+                    full = buf if per * world == half else torch.cat(
+                        [buf[r * per:r * per + (b - a)] for r, (a, b) in enumerate(bounds)])
+                else:
+                    full = buf[:half]
+                self.ctx._check(lib.lf_sampler_half_accept(self._h, h, ct.c_void_p(full.data_ptr()), ct.c_void_p(stream)))
+        self._keep = buf
+
     def sync(self):
         lib = self.ctx._lib
         t = int(lib.lf_sampler_steps(self._h))

@@ -112,3 +112,71 @@ def test_device_sampler_recovers_a_posterior():
     assert 0.05 < ds.acceptance_fraction.mean() < 0.95
     assert np.all(np.isfinite(ds.acor))
     ds.close(); ctx.close()
+
+
+def test_sharded_form_gives_the_same_chain_single_rank():
+    from lumfuncmcmc_amd.capi import LFContext
+    from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
+    inp = make_inputs("free", 2500, seed=51)
+    ctx = LFContext(inp)
+    W, nsteps, seed = 24, 12, 99
+    pos = synth.walkers("free", W, seed=52)
+    a = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
+    a.run_mcmc(pos, nsteps)
+    b = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
+    b.enqueue_sharded(pos, nsteps)
+    b.sync()
+    assert np.array_equal(a.chain, b.chain) and np.array_equal(a.lnprobability, b.lnprobability)
+    assert np.array_equal(a.naccepted, b.naccepted)
+    a.close(); b.close(); ctx.close()
+
+
+def _sharded_worker(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)                      # rehearsal on a one-GPU box: every rank shares device 0
+    from lf_testlib import make_inputs, synth
+    from lumfuncmcmc_amd.capi import LFContext
+    from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
+    inp = make_inputs("zevol", 3000, seed=61)
+    ctx = LFContext(inp)
+    W, nsteps, seed = 22, 8, 1234               # half = 11: ragged over 2 ranks (6 + 5)
+    pos = synth.walkers("zevol", W, seed=62)
+    s = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
+    s.enqueue_sharded(pos, nsteps)
+    s.sync()
+    ref = None
+    if rank == 0:
+        f = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
+        f.run_mcmc(pos, nsteps)
+        ref = (f.chain, f.lnprobability)
+        f.close()
+    q.put((rank, s.chain, s.lnprobability, ref))
+    dist.barrier()
+    s.close(); ctx.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_sampler_two_ranks_on_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, c0, l0, ref), (_, c1, l1, _) = res
+    assert np.array_equal(c0, c1) and np.array_equal(l0, l1)          # ranks stay in lock-step
+    assert np.array_equal(c0, ref[0]) and np.array_equal(l0, ref[1])  # and reproduce the one-GPU chain
