@@ -207,6 +207,19 @@ def main():
                           "n_sources": args.nsrc, "walkers_per_gpu": W, "variant": args.variant,
                           "parallelism": "walker-sharded x%d, RCCL all-gather of lnprob" % world},
                "roofline": roofline}
+        if world == 1:
+            # the same workload as real MCMC: the device-resident sampler (theta, accept/reject and the
+            # chain stay in HBM; six launches per ensemble step, no host in the loop)
+            from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
+            nst = max(10, args.steps)
+            ds = DeviceEnsembleSampler(ctx, W, seed=1, capacity=nst + 3)
+            ds.run_mcmc(theta_all[:2].reshape(-1, ndim)[:W], 3)
+            t1 = time.perf_counter()
+            ds.run_mcmc(None, nst)
+            t2 = time.perf_counter() - t1
+            res["mcmc_device_sampler"] = {"value": W * nst / t2, "unit": "walker-lnprob evals/s", "ms_per_step": t2 / nst * 1e3,
+                                          "steps": nst, "acceptance_fraction": float(ds.acceptance_fraction.mean())}
+            ds.close()
         if world == 1 and not args.no_cpu_baseline:
             cb, ref = cpu_baseline(model, args.variant, theta_all[(2 * (args.steps - 1)) % nblk], args.cpu_budget)
             got = out[0].cpu().numpy()[:len(ref)]
