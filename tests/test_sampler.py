@@ -54,3 +54,23 @@ def test_same_seed_same_chain():
     a = EnsembleSampler(8, 2, f, seed=7); a.run_mcmc(p0, 20)
     b = EnsembleSampler(8, 2, f, seed=7); b.run_mcmc(p0, 20)
     assert np.array_equal(a.chain, b.chain)
+
+
+def test_config1_cpu_plumbing():
+    """BASELINE config 1 on the CPU: 1k synthetic sources, 32 walkers, 50 steps, the NumPy path (the
+    oracle stands in for lnprob here - test infrastructure - to exercise the sampler and the sample
+    bookkeeping of fit_model without a GPU)."""
+    import os
+    import lf_oracle as O
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixcomp_n1000.npz"))
+    inp = O.inputs_from_golden(g, "fixcomp")
+    rng = np.random.default_rng(0)
+    p0 = np.array([42.5, -2.0, -1.49]) + 0.05 * rng.normal(size=(32, 3))
+    s = EnsembleSampler(32, 3, lambda b: O.lnprob_batch(inp, b), seed=4)
+    s.run_mcmc(p0, 50)
+    assert s.chain.shape == (32, 50, 3) and np.isfinite(s.lnprobability).all()
+    tau = np.max(s.acor)
+    burn = min(int(tau * 3), 25)
+    samples = np.concatenate([s.chain, s.lnprobability[:, :, None]], axis=2)[:, burn:, :].reshape(-1, 4)
+    assert samples.shape[1] == 4 and samples.shape[0] == 32 * (50 - burn)
+    assert s.nevals == 32 * 51
