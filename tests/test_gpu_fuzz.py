@@ -1,0 +1,47 @@
+"""Seeded random configurations (sizes, field layouts, grid sides, batch sizes, variants, forced launch
+geometries) against the oracle: the ragged and degenerate shapes nobody writes by hand."""
+import numpy as np
+import pytest
+
+from lf_testlib import O, compare_rows, make_inputs, synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(seed):
+    from lumfuncmcmc_amd.capi import LFContext
+    rng = np.random.default_rng(1000 + seed)
+    variant = ("free", "fixcomp", "zevol")[seed % 3]
+    nf = int(rng.integers(1, 9))
+    n = int(rng.choice([1, 2, 7, 63, 255, 256, 257, 511, 2047, 2048, 2049, 4500]))
+    S = int(rng.integers(4, 40))
+    fsa = bool(rng.integers(0, 2))
+    inp = make_inputs(variant, n, seed=seed, S=S, fix_sch_al=fsa, nf=nf,
+                      pivots=(1.18, 1.36, 1.54) if seed % 2 else (1.20, 1.53, 1.86))
+    # ragged fields: random cut points, some fields empty
+    cuts = np.sort(rng.integers(0, n + 1, nf - 1)) if nf > 1 else np.array([], dtype=int)
+    inp["field_ind"] = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    if variant != "free":
+        # Om_arr was built for the equal split: rebuild it for the ragged one
+        om0 = np.zeros(n, dtype=int); fl = np.zeros(n)
+        for f in range(nf):
+            om0[inp["field_ind"][f]:inp["field_ind"][f + 1]] = inp["Omega_0"][f]
+            fl[inp["field_ind"][f]:inp["field_ind"][f + 1]] = inp["Flim0"][f]
+        with np.errstate(all="ignore"):
+            inp["Om_arr"] = O.omega(inp["lum"], inp["DLz"], om0, 1.0e-17 * fl, synth.ALPHA_C, synth.FCMIN)
+    B = int(rng.integers(1, 70))
+    th = synth.walkers(variant, B, seed=seed + 7, fix_sch_al=fsa, nf=nf)
+    # a few rows outside the box / in the underflow zone / NaN
+    if B > 3:
+        th[0, 0] = 40.2
+        th[1, 1] = 5.5
+        th[2, -1] = np.nan
+    ref = O.lnprob_batch(inp, th)
+    ctx = LFContext(inp)
+    for gi in (-1, int(rng.integers(0, 6))):
+        ctx.set_option("geometry", gi)
+        got = ctx.lnprob_batch(th)
+        compare_rows(got, ref, inp, th, RTOL, "seed %d geo %d" % (seed, gi))
+    ctx.close()
