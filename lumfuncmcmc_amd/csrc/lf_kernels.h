@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
             quad_range(aL, bL, cL, kc.z_lo[f], kc.z_hi[f], lsmn, lsmx);
             quad_range(aP, bP, cP, kc.z_lo[f], kc.z_hi[f], phmn, phmx);
             const double tmax = kc.lum_max[f] - lsmn, tmin = kc.lum_min[f] - lsmx;
-            const double vb = pow(10.0, tmax);
+            const double vb = exp10(tmax);
             const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
             m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
             // closed-form part: sum_i [ln Om_i + ln ln10 + ln10 phi*(z_i) + c1 (lum_i - L*(z_i))]; only
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
         ok = ok && (al >= kc.lims[LF_LIM_SCH_AL][0]) && (al <= kc.lims[LF_LIM_SCH_AL][1]);
         ok = ok && (alphaC >= kc.lims[LF_LIM_ALPHA][0]) && (alphaC <= kc.lims[LF_LIM_ALPHA][1]);
         const double c0 = LF_LNLN10 + LF_LN10 * phistar, c1 = LF_LN10 * (al + 1.0);
-        const double Q = pow(10.0, LF_LREF - Lstar);
+        const double Q = exp10(LF_LREF - Lstar);
         if (live && f == 0) {
             r[R_LSTAR] = Lstar;
             r[R_C0] = c0;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
             if (kc.variant == LF_FREE) {
                 const double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
                 lF = log10(1.0e-17 * Flim);
-                V = 1.0 / (Flim * pow(10.0, b));
+                V = 1.0 / (Flim * exp10(b));
                 if (live) {
                     r[R_LF + f] = lF;
                     r[R_V + f] = V;
@@ -439,6 +439,16 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     const int w0 = tile * tw;                       // tw <= TW walkers per tile (TW sizes the LDS buffer)
     const int nw = min(tw, B - w0);
 
+    if (VARIANT == LF_FIXCOMP) {
+        // piece A is closed-form (wbase): unless one of the tile's walkers needs the per-term underflow
+        // checks there is nothing to do here - do not even read the catalogue
+        int any_slow = 0;
+        for (int w = 0; w < nw; ++w) any_slow |= (wmode[(size_t)(w0 + w) * MAXF + fld] == MODE_SLOW);
+        if (!__builtin_amdgcn_readfirstlane(any_slow)) {
+            if (tid < nw) partial[(size_t)(w0 + tid) * pstride + c] = 0.0;
+            return;
+        }
+    }
     // items -> registers (lanes past the end replay the chunk's first source with weight 0)
     double lum[ST], a1[ST], pp[ST], uu[ST], wgt[ST];
 #pragma unroll
