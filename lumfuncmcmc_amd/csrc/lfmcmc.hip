@@ -114,7 +114,7 @@ struct Geo {
     int st, tw, twb;     // sources per lane, walkers per source workgroup, walkers per grid workgroup
 };
 // instantiated geometries; [0] and [1] are the defaults for large and small problems
-constexpr Geo GEOS[] = {{8, 16, 16}, {2, 8, 2}, {8, 8, 8}, {8, 4, 4}, {4, 8, 4}, {4, 4, 4}};
+constexpr Geo GEOS[] = {{8, 16, 16}, {2, 8, 2}, {8, 8, 8}, {8, 4, 4}, {4, 8, 4}, {4, 4, 4}, {6, 16, 16}, {4, 16, 16}};
 constexpr int NGEO = sizeof(GEOS) / sizeof(GEOS[0]);
 
 int pick_geometry(const lf_ctx* c, int B) {
@@ -204,7 +204,9 @@ void launch_main(lf_ctx* c, int gi, dim3 grid, int ntiles, int tw, int ntilesB, 
         case 2: launch_geo<VARIANT, 2>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
         case 3: launch_geo<VARIANT, 3>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
         case 4: launch_geo<VARIANT, 4>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        default: launch_geo<VARIANT, 5>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+        case 5: launch_geo<VARIANT, 5>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 6: launch_geo<VARIANT, 6>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        default: launch_geo<VARIANT, 7>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
     }
 }
 
