@@ -330,6 +330,31 @@ def main():
         T2.add_row(["OIII", 42.123456, 42.5])
         T2.write(os.path.join(OUT, "fwtl_formats.dat"), format="ascii.fixed_width_two_line", overwrite=True,
                  formats={"Line": "%s", names[1]: "%0.3f", names[2]: "%0.3f"})
+    # ---- end to end at BASELINE sizes: only the generator arguments, theta and the reference's lnprob
+    #      are stored (a few KB) - the test rebuilds the catalogue with synth.catalogue and goes through
+    #      the build's own host setup, so setup + kernels are compared with the reference together
+    if only in (None, "e2e"):
+        for (variant, n, seed, zsl, nrows) in (("free", 100000, 20241016, 0, 12), ("free", 1000000, 20241016, 0, 12),
+                                               ("fixcomp", 1000000, 20241016, 0, 12), ("zevol", 800000, 20241016, 8, 12)):
+            cat = S.catalogue(n, seed=seed, zslices=zsl)
+            kw = ctor_kwargs(cat, False, variant == "fixcomp", 0.0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                with np.errstate(all="ignore"):
+                    if variant == "zevol":
+                        for k in ("fix_comp", "Flim_lims", "alpha_lims", "diff_rand"):
+                            kw.pop(k)
+                        o = RZ.LumFuncMCMCz(S.split_fields(cat["z"], cat["field_ind"]), **kw)
+                        f = o.lnprob
+                    else:
+                        o = R.LumFuncMCMC(S.split_fields(cat["z"], cat["field_ind"]), **kw)
+                        f = o.lnprob_fix_comp if variant == "fixcomp" else o.lnprob
+                    th = S.walkers(variant, nrows, seed=1)
+                    if variant != "zevol":
+                        th[-1, 0] = 40.3          # one row in the underflow zone
+                    lnp = np.array([f(np.array(t)) for t in th])
+            save("e2e_%s_n%d" % (variant, n), dict(variant=variant, n=n, seed=seed, zslices=zsl, theta=th, lnprob=lnp))
+            print(variant, n, lnp[:3])
     if only:
         with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)

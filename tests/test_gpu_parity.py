@@ -298,3 +298,35 @@ def test_class_surface_fixcomp_and_z():
     oz.fit_model()
     assert oz.samples.shape[1] == 8
     oz.close()
+
+
+@pytest.mark.parametrize("name", ["e2e_free_n100000", "e2e_free_n1000000", "e2e_fixcomp_n1000000", "e2e_zevol_n800000"])
+def test_end_to_end_against_the_reference_at_baseline_sizes(name):
+    """BASELINE sizes, the reference itself as the oracle: the fixture holds only the generator arguments,
+    theta and the lnprob the reference returned (oracle/gen_golden.py --only e2e).  Here the catalogue is
+    regenerated, the build's own host setup (cosmology, tables, splines) makes the kernel inputs, and the
+    HIP path evaluates them: setup and kernels are compared with the reference together."""
+    from lumfuncmcmc_amd.model import LumFuncMCMC, LumFuncMCMCz
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    variant, n = str(g["variant"]), int(g["n"])
+    cat = synth.catalogue(n, seed=int(g["seed"]), zslices=int(g["zslices"]))
+    fi = cat["field_ind"]
+    kw = dict(lum=synth.split_fields(cat["lum"], fi), lum_e=synth.split_fields(cat["lum_e"], fi),
+              Flim=list(synth.FLIM), alpha=synth.ALPHA_C, Omega_0=list(synth.OMEGA_0), sch_al=synth.SCH_AL,
+              sch_al_lims=synth.SCH_AL_LIMS, Lstar=synth.LSTAR, Lstar_lims=synth.LSTAR_LIMS,
+              phistar=synth.PHISTAR, phistar_lims=synth.PHISTAR_LIMS, Lc=synth.LC, Lh=synth.LH, nwalkers=32,
+              nsteps=10, min_comp_frac=0.0, field_ind=fi)
+    zs = synth.split_fields(cat["z"], fi)
+    if variant == "zevol":
+        o = LumFuncMCMCz(zs, **kw)
+        got = o.lnprob(g["theta"])
+    else:
+        o = LumFuncMCMC(zs, fix_comp=(variant == "fixcomp"), Flim_lims=synth.FLIM_LIMS, alpha_lims=synth.ALPHA_LIMS, **kw)
+        got = o.lnprob_fix_comp(g["theta"]) if variant == "fixcomp" else o.lnprob(g["theta"])
+    ref = g["lnprob"]
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    rel = np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])
+    print("%s worst rel %.2e" % (name, rel.max()))
+    assert rel.max() < RTOL
+    o.close()
