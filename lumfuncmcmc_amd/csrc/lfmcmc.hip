@@ -47,6 +47,7 @@ struct lf_ctx {
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
+    int64_t opt_skip_grid = 0;          // 1: leave piece B out (source-sharded ranks other than the first)
     // workspace
     int cap_B = 0;                      // padded walker capacity
     size_t cap_partA = 0, cap_partB = 0;
@@ -223,8 +224,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     int rc = get_chunks(c, geo.st * BLOCK, &ct);
     if (rc != LF_OK) return rc;
     const int nchA = ct->n;
-    const int nchB = (c->nnodes + BLOCK - 1) / BLOCK;
-    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * nchB);
+    const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + BLOCK - 1) / BLOCK;
+    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1));
     if (rc != LF_OK) return rc;
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
@@ -249,7 +250,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         const int ntilesB = (B + twb - 1) / twb;
         const int nblkB = nchB * ntilesB;
         dim3 grid((unsigned)(nblkB + nchA * ntiles));     // 1-D: B workgroups first, then A (chunk, tile) per XCD
-        switch (c->kc.variant) {
+        if (grid.x > 0) switch (c->kc.variant) {
             case LF_FREE: launch_main<LF_FREE>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
             case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
             default: launch_main<LF_ZEVOL>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
@@ -606,6 +607,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             return LF_ERR_ARG;
         }
         c->opt_geometry = value;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "skip_grid") == 0) {
+        c->opt_skip_grid = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "walker_tile") == 0) {

@@ -77,3 +77,64 @@ class ShardedLnProb(object):
     def __call__(self, theta):
         t = self.torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64)).to(self.device)
         return self.evaluate_tensor(t.reshape(-1, self.ndim)).cpu().numpy()
+
+
+def shard_sources(inp, rank, world):
+    """Kernel inputs (LFContext's dict) of rank `rank` when the CATALOGUE is sharded: every field's
+    sources are cut in `world` contiguous pieces and the rank keeps its piece of each field, so field
+    membership survives; grids and parameters are replicated."""
+    fi = np.asarray(inp["field_ind"], dtype=np.int64)
+    sel, new_fi = [], [0]
+    for f in range(len(fi) - 1):
+        n = int(fi[f + 1] - fi[f])
+        b, _ = slice_bounds(n, world)
+        lo, hi = b[rank]
+        sel.append(np.arange(fi[f] + lo, fi[f] + hi))
+        new_fi.append(new_fi[-1] + (hi - lo))
+    sel = np.concatenate(sel) if sel else np.zeros(0, dtype=np.int64)
+    out = dict(inp)
+    for k in ("lum", "z", "DLz", "Om_arr", "logf"):
+        if out.get(k) is not None:
+            out[k] = np.asarray(out[k])[sel]
+    out["field_ind"] = np.array(new_fi, dtype=np.int64)
+    return out
+
+
+class SourceShardedLnProb(object):
+    """The other way to use several GPUs (for batches smaller than a walker tile per GPU):
+    every rank holds 1/world of the catalogue and evaluates ALL theta rows on it; the per-source sums
+    (and the closed-form walker part, itself a sum over sources) add up, the expected-count integral is
+    computed on rank 0 only, and one all-reduce(SUM) of B doubles gives lnprob on every rank.  A row
+    outside the prior or underflowing on any rank is -inf on that rank, hence in the sum.  Only the
+    summation order differs from the single-GPU result."""
+
+    def __init__(self, inp, device, group=None):
+        import torch
+        import torch.distributed as dist
+        from .capi import LFContext
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device("cuda", device)
+        self.ctx = LFContext(shard_sources(inp, self.rank, self.world), device=device)
+        if self.rank != 0:
+            self.ctx.set_option("skip_grid", 1)
+        self.ndim = self.ctx.ndim
+        self._sync = dist.is_initialized() and dist.get_backend(group) != "nccl"
+
+    def evaluate_tensor(self, theta):
+        out = self.ctx.lnprob_torch(theta)
+        if self.world > 1:
+            if self._sync:
+                self.torch.cuda.current_stream(self.device).synchronize()     # gloo rehearsal, see ShardedLnProb
+            self.dist.all_reduce(out, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self._sync:
+                self.torch.cuda.synchronize(self.device)
+        return out
+
+    def __call__(self, theta):
+        t = self.torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64)).to(self.device)
+        return self.evaluate_tensor(t.reshape(-1, self.ndim)).cpu().numpy()
+
+    def close(self):
+        self.ctx.close()

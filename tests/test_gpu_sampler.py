@@ -180,3 +180,59 @@ def test_sharded_sampler_two_ranks_on_one_gpu():
     (_, c0, l0, ref), (_, c1, l1, _) = res
     assert np.array_equal(c0, c1) and np.array_equal(l0, l1)          # ranks stay in lock-step
     assert np.array_equal(c0, ref[0]) and np.array_equal(l0, ref[1])  # and reproduce the one-GPU chain
+
+
+def _srcshard_worker(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from lf_testlib import make_inputs, synth
+    from lumfuncmcmc_amd.capi import LFContext
+    from lumfuncmcmc_amd.dist import SourceShardedLnProb
+    out = {}
+    for variant in ("free", "fixcomp", "zevol"):
+        inp = make_inputs(variant, 5003, seed=71)
+        th = synth.walkers(variant, 9, seed=72)
+        th[3, 0] = 40.2                          # underflows on the rank that holds the brightest source
+        th[4, 1] = 6.0                           # outside the prior
+        sh = SourceShardedLnProb(inp, 0)
+        got = sh(th)
+        sh.close()
+        ref = None
+        if rank == 0:
+            c = LFContext(inp)
+            ref = c.lnprob_batch(th)
+            c.close()
+        out[variant] = (got, ref)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_source_sharded_lnprob_two_ranks_on_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_srcshard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for variant in ("free", "fixcomp", "zevol"):
+        g0, ref = res[0][1][variant]
+        g1, _ = res[1][1][variant]
+        assert np.array_equal(g0, g1)                               # the all-reduce gives every rank the same sums
+        assert np.array_equal(np.isinf(g0), np.isinf(ref)) and np.isinf(ref).sum() == 2
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(g0[fin], ref[fin], rtol=1e-13)   # only the summation order differs
