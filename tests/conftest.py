@@ -18,3 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """The shared library is a build artefact (git-ignored): make sure the tests see one that matches
+    the sources.  Building is not a fallback - without hipcc and without a library the GPU tests fail."""
+    try:
+        from lumfuncmcmc_amd import build
+        if build.is_stale():
+            build.build_library(verbose=False)
+    except Exception as e:                      # no hipcc here: leave it to the tests to say so
+        sys.stderr.write("conftest: could not (re)build liblfmcmc.so: %s\n" % e)
