@@ -67,7 +67,16 @@ class ShardedLnProb(object):
                 out.copy_(res)
         if not self._inplace and self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()        # gloo (rehearsal) does not order with our launches
-        dist.all_gather_into_tensor(full, mine, group=self.group)
+        try:
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        except RuntimeError:
+            if not self._inplace:
+                raise
+            # a backend build that refuses the in-place form: gather from a separate input from now on
+            self._inplace = False
+            sep = self._buffers.setdefault(("in", B), torch.empty((per,), dtype=torch.float64, device=self.device))
+            sep.copy_(mine)
+            dist.all_gather_into_tensor(full, sep, group=self.group)
         if not self._inplace and self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         if per * self.world == B:
