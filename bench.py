@@ -77,6 +77,23 @@ def cpu_baseline(model, variant, theta, budget_s=20.0):
                       "(DL(z_i) hoisted out of the call, which the reference does not do)" % (n, dt)}, np.array(vals)
 
 
+def cpu_baseline_allcores(model, theta, nthreads):
+    """The C restatement (oracle/lf_oracle.c, OpenMP over theta rows) on all the host cores this process
+    may use: the second CPU figure SURVEY.md section 8d asks for.  Bounded: 4 rows per thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from lf_oracle_c import COracle
+    inp = model.kernel_inputs()
+    inp["lims"] = {k: list(v) for k, v in inp["lims"].items()}
+    co = COracle(inp)
+    rows = np.resize(theta, (4 * nthreads, theta.shape[1]))
+    co.lnprob_batch(rows[:nthreads], nthreads=nthreads)            # warm
+    t0 = time.perf_counter()
+    co.lnprob_batch(rows, nthreads=nthreads)
+    dt = time.perf_counter() - t0
+    return {"value": len(rows) / dt, "unit": "walker-lnprob evals/s", "cores": nthreads, "kind": "port",
+            "sample": "%d theta rows of the timed workload over %d OpenMP threads, %.1f s, plain-C scalar loop" % (len(rows), nthreads, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +242,12 @@ def main():
             got = out[0].cpu().numpy()[:len(ref)]
             cb["max_rel_diff_gpu_vs_port"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
             res["cpu_baseline"] = cb
+            try:
+                # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe the quota)
+                nthr = int(os.environ.get("LF_BENCH_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+                res["cpu_baseline_allcores"] = cpu_baseline_allcores(model, theta_all[0], nthr)
+            except Exception as e:            # the extra figure must never cost the bench line
+                res["cpu_baseline_allcores"] = {"error": str(e)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
