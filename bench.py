@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--geometry", type=int, default=-1)
     ap.add_argument("--walker-tile", type=int, default=0)
+    ap.add_argument("--no-taper", action="store_true")
     ap.add_argument("--default-stream", action="store_true", help="launch on the legacy default stream instead of a side stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
@@ -141,6 +142,8 @@ def main():
         ctx.set_option("geometry", args.geometry)
     if args.walker_tile:
         ctx.set_option("walker_tile", args.walker_tile)
+    if args.no_taper:
+        ctx.set_option("taper", 0)
     ndim = ctx.ndim
     from lumfuncmcmc_amd import synth
     # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled

@@ -125,7 +125,9 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
 
 /* Tuning knobs (performance only, never results beyond summation order):
  * key "geometry": index of the launch geometry (sources per lane x walkers per workgroup),
- * -1 = chosen from N and B; "walker_tile": walkers per workgroup, 0 = the geometry's.
+ * -1 = chosen from N and B; "walker_tile": walkers per workgroup, 0 = the geometry's;
+ * "taper": 1 (default) gives the last ~B/8 walkers quarter-size tiles, dispatched last, so that the
+ * launch drains evenly (bitwise neutral: a tile only decides which workgroup owns a (chunk, walker) sum).
  * One key changes what is computed: "skip_grid" = 1 leaves the expected-count integral (piece B) out
  * of lnprob - for source-sharded ranks other than the first, whose results are summed. */
 int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);

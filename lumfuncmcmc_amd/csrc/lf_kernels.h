@@ -420,24 +420,12 @@ struct SrcArrays {
 
 template <int VARIANT, int ST, int TW>
 __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& sa, const double* __restrict__ wrec,
-                                            const int* __restrict__ wmode, int B, int ntiles, int tw, int id,
-                                            int nblk, double* __restrict__ partial, int pstride,
+                                            const int* __restrict__ wmode, int c, int w0, int nw,
+                                            double* __restrict__ partial, int pstride,
                                             const MathTables& tab, double* __restrict__ red) {
-    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its
-    // own L2.  Renumber so that the ntiles workgroups that read the SAME chunk of the catalogue are
-    // consecutive on ONE XCD: the chunk is fetched from HBM once and served to the others from L2.
-    // (speed only - any placement gives the same result)
+    // one item: catalogue chunk c x walkers w0 .. w0+nw-1 (nw <= TW, which sizes the LDS buffer)
     const int tid = threadIdx.x;
-    int c, tile;
-    {
-        const int q = nblk >> 3, rem = nblk & 7, xcd = id & 7;
-        const int wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
-        c = wg / ntiles;
-        tile = wg - c * ntiles;
-    }
     const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
-    const int w0 = tile * tw;                       // tw <= TW walkers per tile (TW sizes the LDS buffer)
-    const int nw = min(tw, B - w0);
 
     if (VARIANT == LF_FIXCOMP) {
         // piece A is closed-form (wbase): unless one of the tile's walkers needs the per-term underflow
@@ -617,22 +605,53 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
 // at the big geometry (TW walkers x 256 items); the small geometry gives the grid part TWB = 2 walkers
 // per workgroup so that a small batch still spreads over the chip.  B first: it never forms the tail.
 // ----------------------------------------------------------------------------------------------
+// XCD-aware renumbering of a run of n workgroup ids: workgroups are dealt round-robin over the 8 XCDs
+// (id % 8), each with its own L2; the result is an index such that consecutive indices sit on ONE XCD,
+// in dispatch order.  Used so that the tiles which read the SAME catalogue chunk run side by side on
+// one XCD: the chunk comes from HBM once and is served to the others from L2 (speed only).
+__device__ __forceinline__ int xcd_renumber(int id, int n) {
+    const int q = n >> 3, rem = n & 7, xcd = id & 7;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+}
+
+// Tapered walker tiling of the per-source part: walkers [0, B1) in tiles of `tw`, walkers [B1, B) in tiles
+// of `tws` << tw, and the small tiles are dispatched LAST (largest-first): the launch tail is made of
+// quarter-size workgroups, which cuts the drain time of a grid that is only ~4 residency rounds long.
+struct Tiling {
+    int tw, ntiles;        // big tiles
+    int B1, tws, ntiles_s; // small tiles over walkers B1 .. B-1
+};
+
 template <int VARIANT, int ST, int TW, int TWB>
 __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeArrays na,
                                                  const double* __restrict__ wrec, const int* __restrict__ wmode,
-                                                 int B, int ntiles, int tw, int ntilesB, int twb, int nblkB,
+                                                 int B, Tiling tl, int nchA, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
                                                  double* __restrict__ partB, int strideB) {
     __shared__ MathTables tab;
     __shared__ double red[(TW > TWB ? TW : TWB) * BLOCK];
     load_tables(&tab);
     __syncthreads();
-    const int id = blockIdx.x;
-    if (id < nblkB)
+    int id = blockIdx.x;
+    if (id < nblkB) {
         gridsum_body<VARIANT, TWB>(kc, na, wrec, B, ntilesB, twb, id, partB, strideB, tab, red);
-    else
-        srcsum_body<VARIANT, ST, TW>(kc, sa, wrec, wmode, B, ntiles, tw, id - nblkB, (int)gridDim.x - nblkB,
-                                     partA, strideA, tab, red);
+        return;
+    }
+    id -= nblkB;
+    const int nbig = nchA * tl.ntiles;
+    int c, w0, nw;
+    if (id < nbig) {
+        const int wg = xcd_renumber(id, nbig);
+        c = wg / tl.ntiles;
+        w0 = (wg - c * tl.ntiles) * tl.tw;
+        nw = min(tl.tw, tl.B1 - w0);
+    } else {
+        const int wg = xcd_renumber(id - nbig, nchA * tl.ntiles_s);
+        c = wg / tl.ntiles_s;
+        w0 = tl.B1 + (wg - c * tl.ntiles_s) * tl.tws;
+        nw = min(tl.tws, B - w0);
+    }
+    srcsum_body<VARIANT, ST, TW>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
 }
 
 // accept / reject walker k = half*halfW + w with the new lnprob `newlp`, and record it in the chain

@@ -47,6 +47,7 @@ struct lf_ctx {
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
+    int64_t opt_taper = 1;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers
     int64_t opt_skip_grid = 0;          // 1: leave piece B out (source-sharded ranks other than the first)
     // workspace
     int cap_B = 0;                      // padded walker capacity
@@ -189,25 +190,25 @@ struct Prof {
 
 // enqueue the three launches of one batched evaluation on `s`: prepare -> main (A and B) -> finalize
 template <int VARIANT, int GI>
-void launch_geo(lf_ctx* c, dim3 grid, int ntiles, int tw, int ntilesB, int twb, int nblkB, hipStream_t s,
+void launch_geo(lf_ctx* c, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int nblkB, hipStream_t s,
                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
     using namespace lf;
     hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                       na, c->d_wrec, c->d_wmode, B, ntiles, tw, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB);
+                       na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB);
 }
 
 template <int VARIANT>
-void launch_main(lf_ctx* c, int gi, dim3 grid, int ntiles, int tw, int ntilesB, int twb, int nblkB, hipStream_t s,
+void launch_main(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int nblkB, hipStream_t s,
                  const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
     switch (gi) {
-        case 0: launch_geo<VARIANT, 0>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 1: launch_geo<VARIANT, 1>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 2: launch_geo<VARIANT, 2>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 3: launch_geo<VARIANT, 3>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 4: launch_geo<VARIANT, 4>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 5: launch_geo<VARIANT, 5>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 6: launch_geo<VARIANT, 6>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        default: launch_geo<VARIANT, 7>(c, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+        case 0: launch_geo<VARIANT, 0>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 1: launch_geo<VARIANT, 1>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 2: launch_geo<VARIANT, 2>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 3: launch_geo<VARIANT, 3>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 4: launch_geo<VARIANT, 4>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 5: launch_geo<VARIANT, 5>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        case 6: launch_geo<VARIANT, 6>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        default: launch_geo<VARIANT, 7>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
     }
 }
 
@@ -246,14 +247,21 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
             tw = (int)std::min<int64_t>(c->opt_walker_tile, geo.tw);
             twb = (int)std::min<int64_t>(c->opt_walker_tile, geo.twb);
         }
-        const int ntiles = (B + tw - 1) / tw;
+        // tapered tiling: the last ~1/8 of the walkers go in quarter-size tiles that are dispatched last
+        Tiling tl{tw, 0, B, std::max(1, tw / 4), 0};
+        if (c->opt_taper && B >= 2 * tw && tw >= 4) {
+            const int tail = std::max(tw, ((B / 8 + tw - 1) / tw) * tw);       // whole big tiles' worth of walkers
+            tl.B1 = ((B - tail) / tw) * tw;
+        }
+        tl.ntiles = (tl.B1 + tw - 1) / tw;
+        tl.ntiles_s = (B - tl.B1 + tl.tws - 1) / tl.tws;
         const int ntilesB = (B + twb - 1) / twb;
         const int nblkB = nchB * ntilesB;
-        dim3 grid((unsigned)(nblkB + nchA * ntiles));     // 1-D: B workgroups first, then A (chunk, tile) per XCD
+        dim3 grid((unsigned)(nblkB + nchA * (tl.ntiles + tl.ntiles_s)));   // 1-D: B items, big A items, small A items
         if (grid.x > 0) switch (c->kc.variant) {
-            case LF_FREE: launch_main<LF_FREE>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-            default: launch_main<LF_ZEVOL>(c, gi, grid, ntiles, tw, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+            case LF_FREE: launch_main<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+            default: launch_main<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
         }
     }
     {
@@ -607,6 +615,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             return LF_ERR_ARG;
         }
         c->opt_geometry = value;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "taper") == 0) {
+        c->opt_taper = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "skip_grid") == 0) {
