@@ -128,6 +128,12 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * -1 = chosen from N and B; "walker_tile": walkers per workgroup, 0 = the geometry's;
  * "taper": 1 (default) gives the last ~B/8 walkers quarter-size tiles, dispatched last, so that the
  * launch drains evenly (bitwise neutral: a tile only decides which workgroup owns a (chunk, walker) sum).
+ * "compress": 1 = take piece A from the COMPRESSED CATALOGUE (FREE, ZEVOL; off by default): the ~N sources of a
+ * field are replaced by K = 16 weighted pseudo-sources per bin of the one coordinate the walker-dependent factor
+ * of a term depends on (log flux; redshift), with bins refined until the bound on the relative error of every
+ * bin sum, over the whole prior box, is below 1e-16 (csrc/lf_compress.h).  lnprob then costs the grid integral
+ * plus a few hundred terms, whatever N is.  Walkers that need the per-source underflow checks are still summed
+ * over the real catalogue.  Built at the first call with value 1 (returns LF_ERR_ARG if the bound cannot be met).
  * One key changes what is computed: "skip_grid" = 1 leaves the expected-count integral (piece B) out
  * of lnprob - for source-sharded ranks other than the first, whose results are summed. */
 int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
@@ -164,6 +170,13 @@ int64_t lf_sampler_steps(const lf_sampler *s);
  * Same random numbers and arithmetic as lf_sampler_run: the chain is identical for any sharding. */
 int lf_sampler_half_eval(lf_sampler *s, int half, int lo, int hi, double *d_newlp, void *hip_stream);
 int lf_sampler_half_accept(lf_sampler *s, int half, const double *d_newlp, void *hip_stream);
+
+/* Host-only helper behind "compress", exported for tests (touches no GPU): compress n coordinates `key` with
+ * weights `wt` (NULL = 1) into pseudo-sources.  kind 0 (FREE): params = {|a/(1-a)|, alpha_lo, alpha_hi, flim_lo,
+ * flim_hi}; kind 1 (ZEVOL): params = {L_lo, L_hi, z1, z2, z3}.  Returns the number of pseudo-sources (written to
+ * node / weight when it is <= cap), or a negative code; *bound = the accepted error bound. */
+int64_t lf_compress_keys(int kind, const double *params, const double *key, const double *wt, int64_t n,
+                         double *node, double *weight, int64_t cap, double *bound);
 
 /* Last error message of this context (or of lf_create when ctx == NULL).  Never NULL. */
 const char *lf_last_error(const lf_ctx *ctx);

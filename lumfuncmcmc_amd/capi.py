@@ -43,7 +43,7 @@ EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_ba
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
-           "lf_sampler_half_accept")
+           "lf_sampler_half_accept", "lf_compress_keys")
 
 _lib = None
 
@@ -108,6 +108,9 @@ def load():
     lib.lf_sampler_half_eval.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.lf_sampler_half_accept.restype = ctypes.c_int
     lib.lf_sampler_half_accept.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.lf_compress_keys.restype = ctypes.c_int64
+    lib.lf_compress_keys.argtypes = [ctypes.c_int, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int64,
+                                     _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p]
     v = lib.lf_abi_version()
     if v != LF_ABI_VERSION:
         raise RuntimeError("liblfmcmc.so ABI %d != binding ABI %d: rebuild the library" % (v, LF_ABI_VERSION))
@@ -117,6 +120,23 @@ def load():
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def compress_keys(kind, params, key, weight=None):
+    """Host-only helper behind the "compress" option (csrc/lf_compress.h): replace the coordinates `key`
+    (weights `weight`, default 1) by weighted pseudo-sources.  kind 0 = FREE (params = |a/(1-a)|, alpha_lo,
+    alpha_hi, flim_lo, flim_hi), kind 1 = ZEVOL (params = L_lo, L_hi, z1, z2, z3).
+    Returns (node, weight, bound).  Touches no GPU."""
+    lib = load()
+    params, key = _f64(params), _f64(key)
+    wt = _f64(weight) if weight is not None else None
+    cap = key.size + 64
+    node, w = np.empty(cap), np.empty(cap)
+    bound = np.zeros(1)
+    n = lib.lf_compress_keys(int(kind), _ptr(params), _ptr(key), _ptr(wt), key.size, _ptr(node), _ptr(w), cap, _ptr(bound))
+    if n < 0:
+        raise RuntimeError("lf_compress_keys failed (%d): the error bound cannot be met" % n)
+    return node[:n].copy(), w[:n].copy(), float(bound[0])
 
 
 def _ptr(a):

@@ -34,7 +34,7 @@ constexpr int BLOCK = 256;   // 4 waves
 constexpr int REC = 32;      // doubles per walker record
 constexpr int MAXF = 8;
 enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2 };
-enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2 };
+enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4 };   // SLOW: some field of the walker takes the careful path
 
 // walker record, FREE / FIXCOMP
 enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4, R_LF = 8, R_V = 16, R_CA = 24 };   // R_CA = -alpha_C lF
@@ -85,6 +85,19 @@ __device__ __forceinline__ double quad_nofma(double a, double b, double c, doubl
     const double t1 = b * z;
     const double s = t2 + t1;
     return s + c;
+}
+
+// a z^2 + b z + c to ~1 ulp (error-free products and sums, z^2 exact): the compressed catalogue evaluates the
+// quadratic at a few hundred nodes that stand for ~1e6 sources, so it wants the value the reference's per-source
+// roundings scatter around, not one draw of that scatter.
+__device__ __forceinline__ double quad_comp(double a, double b, double c, double z) {
+#pragma clang fp contract(off)
+    const double z2 = z * z, e2 = fma(z, z, -z2);
+    const double p = a * z2, ep = fma(a, z2, -p) + a * e2;
+    const double q = b * z, eq = fma(b, z, -q);
+    const double s = p + q, bs = s - p, es = (p - (s - bs)) + (q - bs);
+    const double r = s + c, br = r - s, er = (s - (r - br)) + (c - br);
+    return r + ((ep + eq) + (es + er));
 }
 
 __device__ inline void quad_range(double a, double b, double c, double lo, double hi, double& mn, double& mx) {
@@ -323,10 +336,11 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     // a walker outside the prior, or already known to be -inf, gets lnprob = -inf whatever its sums are:
     // it must not drag its tile onto the careful path (stretch-move proposals leave the box often)
     if (bad || neginf) m = MODE_FAST;
+    const int slow = group8_or(has_f && m == MODE_SLOW ? 1 : 0);
     if (live && has_f) wmode[(size_t)w * MAXF + f] = m;
     if (live && f == 0) {
         wbase[w] = base;
-        wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0);
+        wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0);
     }
 }
 
@@ -413,12 +427,16 @@ struct SrcArrays {
     const double* a1;     // FREE: logf      FIXCOMP: ln(Om_arr)   ZEVOL: z
     const double* P;      // FREE/FIXCOMP: 10^(lum-42)             ZEVOL: ln(Om_arr)
     const double* U;      // FREE: 10^(logf+17)                    ZEVOL: z^2
+    const double* W;      // compressed catalogue only: weight of the pseudo-source
     const int* chunk_start;
     const int* chunk_len;
     const int* chunk_field;
 };
 
-template <int VARIANT, int ST, int TW>
+// CMP = the items are the pseudo-sources of the compressed catalogue (lfmcmc.hip: build_compressed): each
+// carries a weight, and walkers that need the per-source underflow checks are left out (they are summed over
+// the real catalogue by the rescue workgroups of the same launch).
+template <int VARIANT, int ST, int TW, bool CMP>
 __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& sa, const double* __restrict__ wrec,
                                             const int* __restrict__ wmode, int c, int w0, int nw,
                                             double* __restrict__ partial, int pstride,
@@ -443,7 +461,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     for (int k = 0; k < ST; ++k) {
         const int i = k * BLOCK + tid;
         const size_t g = (size_t)s0 + (i < n ? i : 0);
-        wgt[k] = i < n ? 1.0 : 0.0;
+        wgt[k] = i < n ? (CMP ? sa.W[g] : 1.0) : 0.0;
         lum[k] = sa.lum[g];
         a1[k] = sa.a1[g];
         pp[k] = sa.P[g];
@@ -487,7 +505,10 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 nxC = rn[R_CA + fld];
                 nxV = rn[R_V + fld];
 #pragma unroll
-                for (int k = 0; k < ST; ++k) acc += term_free_fast(wf, a1[k], uu[k], &tab);
+                for (int k = 0; k < ST; ++k) {
+                    const double term = term_free_fast(wf, a1[k], uu[k], &tab);
+                    acc = CMP ? fma(term, wgt[k], acc) : acc + term;
+                }
             } else if (VARIANT == LF_FIXCOMP) {
                 // nothing left per source: piece A is the closed form in wbase
             } else {
@@ -495,11 +516,20 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
 #pragma unroll
                 for (int k = 0; k < ST; ++k) {
-                    const double Ls = quad_nofma(wz.aL, wz.bL, wz.cL, a1[k], uu[k]);      // L*(z_i), lumfuncmcmc_z.py:66
+                    const double Ls = CMP ? quad_comp(wz.aL, wz.bL, wz.cL, a1[k])
+                                          : quad_nofma(wz.aL, wz.bL, wz.cL, a1[k], uu[k]);   // L*(z_i), lumfuncmcmc_z.py:66
                     const double v = fexp_c(LF_LN10 * (lum[k] - Ls), &tab);             // 10^(lum_i - L*(z_i))
                     acc = fma(-v, wgt[k], acc);             // everything else of the term is in wbase
                 }
             }
+        } else if (CMP) {
+            // left to the rescue workgroups (real catalogue); only keep the prefetch chain going
+            if (VARIANT == LF_FREE) {
+                nxA = rn[R_ALPHAC];
+                nxC = rn[R_CA + fld];
+                nxV = rn[R_V + fld];
+            }
+            if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
         } else {
             // careful path (rare): device-library math, per-term underflow checks, -inf poisoning.  Items
             // are re-read from memory inside a rolled loop so that this path adds no register pressure
@@ -559,6 +589,29 @@ struct NodeArrays {
     int nnodes;
 };
 
+// FREE: sum over the fields of Omega_0[f] fc^(1 / decay) at one node, for one walker.  NF is a template parameter
+// so that the loop is straight-line code: the NF chains (rsqrt -> log -> exp -> rcp -> exp) are independent and
+// the scheduler interleaves them, and all the walker constants are fetched by one batch of scalar loads.
+template <int NF>
+__device__ __forceinline__ double field_sum(const KConst& kc, const double* __restrict__ r, double alphaC, double a3,
+                                            double a4, const MathTables* __restrict__ tab) {
+    double lF[NF], V[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        lF[f] = r[R_CA + f];
+        V[f] = r[R_V + f];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const double num = fma(alphaC, a3, lF[f]);                    // alpha_C (logf - lF)
+        const double lnfc = flog_half(fma(num, frsqrt(fma(num, num, 1.0)), 1.0), tab);
+        const double d = fmax(1.0 - fexp_c(-(a4 * V[f]), tab), 1e-300);
+        s = fma(kc.om0_grid[f], fexp_c(lnfc * frcp(d), tab), s);      // fc ** (1 / fc_decay)
+    }
+    return s;
+}
+
 template <int VARIANT, int TW>
 __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays& na, const double* __restrict__ wrec,
                                              int B, int ntiles, int tw, int id, double* __restrict__ partial,
@@ -579,11 +632,16 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
         if (VARIANT == LF_FREE) {
             const double T = fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
             const double alphaC = r[R_ALPHAC];
-            double s = 0.0;
-            for (int f = 0; f < kc.nf; ++f) {
-                const double lnfc = ln_fc_fast(alphaC * (a3 - r[R_LF + f]), &tab);
-                const double d = fmax(1.0 - fexp_c(-(a4 * r[R_V + f]), &tab), 1e-300);
-                s = fma(kc.om0_grid[f], fexp_c(lnfc * frcp(d), &tab), s);          // fc ** (1 / fc_decay)
+            double s;
+            switch (kc.nf) {
+                case 1: s = field_sum<1>(kc, r, alphaC, a3, a4, &tab); break;
+                case 2: s = field_sum<2>(kc, r, alphaC, a3, a4, &tab); break;
+                case 3: s = field_sum<3>(kc, r, alphaC, a3, a4, &tab); break;
+                case 4: s = field_sum<4>(kc, r, alphaC, a3, a4, &tab); break;
+                case 5: s = field_sum<5>(kc, r, alphaC, a3, a4, &tab); break;
+                case 6: s = field_sum<6>(kc, r, alphaC, a3, a4, &tab); break;
+                case 7: s = field_sum<7>(kc, r, alphaC, a3, a4, &tab); break;
+                default: s = field_sum<8>(kc, r, alphaC, a3, a4, &tab);
             }
             val = W * T * s;
         } else if (VARIANT == LF_FIXCOMP) {
@@ -622,12 +680,23 @@ struct Tiling {
     int B1, tws, ntiles_s; // small tiles over walkers B1 .. B-1
 };
 
-template <int VARIANT, int ST, int TW, int TWB>
+// Compressed-catalogue launches (CMP) append `nresc` rescue workgroups: they do nothing unless lf_prepare
+// flagged a walker STAT_SLOW, and then sum that walker over the REAL catalogue `sd` (chunk r, r + nresc, ...)
+// into partR[w][chunk] with the per-source path - such a walker's result is the direct path's (same code, same
+// per-term checks; bitwise when the direct path runs with the same chunk size).
+struct Rescue {
+    SrcArrays sd;
+    const int* wstat;
+    double* partR;
+    int nchD, nresc;
+};
+
+template <int VARIANT, int ST, int TW, int TWB, bool CMP>
 __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeArrays na,
                                                  const double* __restrict__ wrec, const int* __restrict__ wmode,
                                                  int B, Tiling tl, int nchA, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
-                                                 double* __restrict__ partB, int strideB) {
+                                                 double* __restrict__ partB, int strideB, Rescue rs) {
     __shared__ MathTables tab;
     __shared__ double red[(TW > TWB ? TW : TWB) * BLOCK];
     load_tables(&tab);
@@ -639,6 +708,22 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
     }
     id -= nblkB;
     const int nbig = nchA * tl.ntiles;
+    if (CMP && id >= nbig + nchA * tl.ntiles_s) {
+        const int r = id - (nbig + nchA * tl.ntiles_s);
+        for (int wb = 0; wb < B; wb += 64) {
+            const int wl = wb + (threadIdx.x & 63);
+            unsigned long long todo = __ballot(wl < B && (rs.wstat[wl < B ? wl : 0] & STAT_SLOW));   // the same in all four waves
+            while (todo) {
+                const int w = wb + __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                for (int c = r; c < rs.nchD; c += rs.nresc) {
+                    srcsum_body<VARIANT, ST, TW, false>(kc, rs.sd, wrec, wmode, c, w, 1, rs.partR, rs.nchD, tab, red);
+                    __syncthreads();
+                }
+            }
+        }
+        return;
+    }
     int c, w0, nw;
     if (id < nbig) {
         const int wg = xcd_renumber(id, nbig);
@@ -651,7 +736,7 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
         w0 = tl.B1 + (wg - c * tl.ntiles_s) * tl.tws;
         nw = min(tl.tws, B - w0);
     }
-    srcsum_body<VARIANT, ST, TW>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
+    srcsum_body<VARIANT, ST, TW, CMP>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
 }
 
 // accept / reject walker k = half*halfW + w with the new lnprob `newlp`, and record it in the chain
@@ -707,6 +792,7 @@ __global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __r
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,
                                                   const double* __restrict__ partB, int nchB, int strideB,
+                                                  const double* __restrict__ partR, int nchR,
                                                   const int* __restrict__ wstat,
                                                   const double* __restrict__ wbase, int B, AcceptArgs ap,
                                                   double* __restrict__ out, double* __restrict__ outA,
@@ -715,8 +801,11 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
     if (w >= B) return;
     const int lane = threadIdx.x;
     double a = 0.0, b = 0.0;
-    const double* pa = partA + (size_t)w * strideA;
+    // compressed catalogue: a walker flagged SLOW was summed over the real catalogue by the rescue workgroups
+    const bool resc = partR != nullptr && (wstat[w] & STAT_SLOW);
+    const double* pa = resc ? partR + (size_t)w * nchR : partA + (size_t)w * strideA;
     const double* pb = partB + (size_t)w * strideB;
+    if (resc) nchA = nchR;
     // four independent running sums per lane so that the loads are in flight together (latency kernel)
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int c = lane;

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "lf_compress.h"
 #include "lf_kernels.h"
 
 namespace {
@@ -33,6 +34,17 @@ struct EventPair {
     int kind;
 };
 
+// compressed catalogue (lf_compress.h): weighted pseudo-sources, sources of a field contiguous
+struct CompressedCat {
+    bool built = false;
+    int64_t n = 0;
+    std::vector<int64_t> field_ind;
+    double *d_lum = nullptr, *d_a1 = nullptr, *d_U = nullptr, *d_W = nullptr;
+    std::map<int, ChunkTable> chunks;
+    int nbins = 0;
+    double bound = 0.0;
+};
+
 }  // namespace
 
 struct lf_ctx {
@@ -49,6 +61,10 @@ struct lf_ctx {
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     int64_t opt_taper = 1;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers
     int64_t opt_skip_grid = 0;          // 1: leave piece B out (source-sharded ranks other than the first)
+    int64_t opt_compress = 0;           // 1: piece A from the compressed catalogue (FREE, ZEVOL)
+    CompressedCat cmp;
+    double* d_partR = nullptr;          // rescue partials [B][chunks of the real catalogue]
+    size_t cap_partR = 0;
     // workspace
     int cap_B = 0;                      // padded walker capacity
     size_t cap_partA = 0, cap_partB = 0;
@@ -86,17 +102,18 @@ int upload(lf_ctx* c, T** dst, const T* src, size_t n) {
     return LF_OK;
 }
 
-int get_chunks(lf_ctx* c, int ch, ChunkTable** out) {
-    auto it = c->chunks.find(ch);
-    if (it != c->chunks.end()) {
+int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<int64_t>& field_ind, int ch,
+               ChunkTable** out) {
+    auto it = tables.find(ch);
+    if (it != tables.end()) {
         *out = &it->second;
         return LF_OK;
     }
     std::vector<int> st, ln, fl;
     for (int f = 0; f < c->kc.nf; ++f) {
-        for (int64_t s = c->field_ind[f]; s < c->field_ind[f + 1]; s += ch) {
+        for (int64_t s = field_ind[f]; s < field_ind[f + 1]; s += ch) {
             st.push_back((int)s);
-            ln.push_back((int)std::min<int64_t>(ch, c->field_ind[f + 1] - s));
+            ln.push_back((int)std::min<int64_t>(ch, field_ind[f + 1] - s));
             fl.push_back(f);
         }
     }
@@ -106,8 +123,8 @@ int get_chunks(lf_ctx* c, int ch, ChunkTable** out) {
     if ((rc = upload(c, &t.d_start, st.data(), st.size())) != LF_OK) return rc;
     if ((rc = upload(c, &t.d_len, ln.data(), ln.size())) != LF_OK) return rc;
     if ((rc = upload(c, &t.d_field, fl.data(), fl.size())) != LF_OK) return rc;
-    c->chunks[ch] = t;
-    *out = &c->chunks[ch];
+    tables[ch] = t;
+    *out = &tables[ch];
     return LF_OK;
 }
 
@@ -116,7 +133,7 @@ struct Geo {
     int st, tw, twb;     // sources per lane, walkers per source workgroup, walkers per grid workgroup
 };
 // instantiated geometries; [0] and [1] are the defaults for large and small problems
-constexpr Geo GEOS[] = {{8, 16, 16}, {2, 8, 2}, {8, 8, 8}, {8, 4, 4}, {4, 8, 4}, {4, 4, 4}, {6, 16, 16}, {4, 16, 16}};
+constexpr Geo GEOS[] = {{8, 16, 16}, {2, 8, 2}, {8, 8, 8}, {8, 4, 4}, {4, 8, 4}, {4, 4, 4}, {6, 16, 16}, {4, 16, 16}, {2, 8, 16}};
 constexpr int NGEO = sizeof(GEOS) / sizeof(GEOS[0]);
 
 int pick_geometry(const lf_ctx* c, int B) {
@@ -128,7 +145,7 @@ int pick_geometry(const lf_ctx* c, int B) {
     return blocks >= 1024 ? 0 : 1;
 }
 
-int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
+int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t partR = 0) {
     if (Bpad > c->cap_B) {
         int nb = std::max(Bpad, c->cap_B * 2);
         LF_HIP(c, hipDeviceSynchronize());
@@ -155,6 +172,13 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB) {
         c->cap_partA = 0;
         LF_HIP(c, hipMalloc((void**)&c->d_partA, partA * sizeof(double)));
         c->cap_partA = partA;
+    }
+    if (partR > c->cap_partR) {
+        LF_HIP(c, hipDeviceSynchronize());
+        hipFree(c->d_partR);
+        c->cap_partR = 0;
+        LF_HIP(c, hipMalloc((void**)&c->d_partR, partR * sizeof(double)));
+        c->cap_partR = partR;
     }
     if (partB > c->cap_partB) {
         LF_HIP(c, hipDeviceSynchronize());
@@ -189,12 +213,26 @@ struct Prof {
 };
 
 // enqueue the three launches of one batched evaluation on `s`: prepare -> main (A and B) -> finalize
-template <int VARIANT, int GI>
+template <int VARIANT, int GI, bool CMP = false>
 void launch_geo(lf_ctx* c, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int nblkB, hipStream_t s,
-                const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
+                const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB,
+                const lf::Rescue& rs = lf::Rescue{}) {
     using namespace lf;
-    hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                       na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB);
+    hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, CMP>), grid, dim3(BLOCK), 0, s, c->kc, sa,
+                       na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB, rs);
+}
+
+// compressed-catalogue launches: the pseudo-sources are few, so only the small-tile geometries are instantiated
+constexpr int CMP_GEOS[] = {8, 1, 4, 2};     // [0] is the default: few sources per lane, 16 walkers per grid workgroup
+template <int VARIANT>
+void launch_main_cmp(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int nblkB, hipStream_t s,
+                     const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB, const lf::Rescue& rs) {
+    switch (gi) {
+        case 1: launch_geo<VARIANT, 1, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 4: launch_geo<VARIANT, 4, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 2: launch_geo<VARIANT, 2, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        default: launch_geo<VARIANT, 8, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
+    }
 }
 
 template <int VARIANT>
@@ -208,7 +246,8 @@ void launch_main(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int t
         case 4: launch_geo<VARIANT, 4>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
         case 5: launch_geo<VARIANT, 5>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
         case 6: launch_geo<VARIANT, 6>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        default: launch_geo<VARIANT, 7>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+        case 7: launch_geo<VARIANT, 7>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+        default: launch_geo<VARIANT, 8>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
     }
 }
 
@@ -219,14 +258,25 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     AcceptArgs ap{};
     if (step) sp = *step;
     if (accept) ap = *accept;
-    const int gi = pick_geometry(c, B);
+    // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
+    const bool cmp = c->opt_compress && c->cmp.built && c->kc.variant != LF_FIXCOMP;
+    int gi = pick_geometry(c, B);
+    if (cmp) {
+        bool ok = false;
+        for (int g : CMP_GEOS) ok = ok || g == gi;
+        if (!ok || c->opt_geometry < 0) gi = CMP_GEOS[0];
+    }
     const Geo geo = GEOS[gi];
-    ChunkTable* ct = nullptr;
-    int rc = get_chunks(c, geo.st * BLOCK, &ct);
+    ChunkTable *ct = nullptr, *ctd = nullptr;
+    int rc = cmp ? get_chunks(c, c->cmp.chunks, c->cmp.field_ind, geo.st * BLOCK, &ct)
+                 : get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ct);
     if (rc != LF_OK) return rc;
+    if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd)) != LF_OK) return rc;
     const int nchA = ct->n;
+    const int nchD = cmp ? ctd->n : 0;
+    const int nresc = cmp ? std::min(nchD, 256) : 0;
     const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + BLOCK - 1) / BLOCK;
-    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1));
+    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * nchD);
     if (rc != LF_OK) return rc;
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
@@ -238,18 +288,38 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
                            c->d_wstat, c->d_wmode, c->d_wbase);
     }
-    SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, ct->d_start, ct->d_len, ct->d_field};
+    const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field};
+    SrcArrays sa = sd;
+    Rescue rs{};
+    if (cmp) {
+        sa = SrcArrays{c->cmp.d_lum, c->cmp.d_a1, c->cmp.d_lum, c->cmp.d_U, c->cmp.d_W, ct->d_start, ct->d_len, ct->d_field};
+        rs.sd = sd;
+        rs.sd.chunk_start = ctd->d_start;
+        rs.sd.chunk_len = ctd->d_len;
+        rs.sd.chunk_field = ctd->d_field;
+        rs.wstat = c->d_wstat;
+        rs.partR = c->d_partR;
+        rs.nchD = nchD;
+        rs.nresc = nresc;
+    }
     NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->nnodes};
     {
         Prof p(c, s, 1);
         int tw = geo.tw, twb = geo.twb;
+        if (cmp && nchB > 0) {
+            // the grid integral is all the work there is: walkers per grid workgroup such that the launch
+            // still has ~2000 workgroups (8 per CU), as many as the instantiation allows otherwise
+            int t = 1;
+            while (t < geo.twb && (int64_t)nchB * ((B + 2 * t - 1) / (2 * t)) >= 2048) t *= 2;
+            twb = t;
+        }
         if (c->opt_walker_tile > 0) {
             tw = (int)std::min<int64_t>(c->opt_walker_tile, geo.tw);
             twb = (int)std::min<int64_t>(c->opt_walker_tile, geo.twb);
         }
         // tapered tiling: the last ~1/8 of the walkers go in quarter-size tiles that are dispatched last
         Tiling tl{tw, 0, B, std::max(1, tw / 4), 0};
-        if (c->opt_taper && B >= 2 * tw && tw >= 4) {
+        if (c->opt_taper && !cmp && B >= 2 * tw && tw >= 4) {
             const int tail = std::max(tw, ((B / 8 + tw - 1) / tw) * tw);       // whole big tiles' worth of walkers
             tl.B1 = ((B - tail) / tw) * tw;
         }
@@ -257,19 +327,92 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         tl.ntiles_s = (B - tl.B1 + tl.tws - 1) / tl.tws;
         const int ntilesB = (B + twb - 1) / twb;
         const int nblkB = nchB * ntilesB;
-        dim3 grid((unsigned)(nblkB + nchA * (tl.ntiles + tl.ntiles_s)));   // 1-D: B items, big A items, small A items
-        if (grid.x > 0) switch (c->kc.variant) {
-            case LF_FREE: launch_main<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-            case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-            default: launch_main<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+        // 1-D grid: B items, big A items, small A items, rescue workgroups
+        dim3 grid((unsigned)(nblkB + nchA * (tl.ntiles + tl.ntiles_s) + nresc));
+        if (grid.x > 0) {
+            if (cmp) {
+                if (c->kc.variant == LF_FREE) launch_main_cmp<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
+                else launch_main_cmp<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
+            } else switch (c->kc.variant) {
+                case LF_FREE: launch_main<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+                case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
+                default: launch_main<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+            }
         }
     }
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB);
+                           cmp ? c->d_partR : nullptr, nchD, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB);
     }
     LF_HIP(c, hipGetLastError());
+    return LF_OK;
+}
+
+void free_cmp(CompressedCat& cc) {
+    for (auto& kv : cc.chunks) {
+        hipFree(kv.second.d_start);
+        hipFree(kv.second.d_len);
+        hipFree(kv.second.d_field);
+    }
+    cc.chunks.clear();
+    double* bufs[] = {cc.d_lum, cc.d_a1, cc.d_U, cc.d_W};
+    for (double* b : bufs)
+        if (b) hipFree(b);
+    cc = CompressedCat{};
+}
+
+// Build the compressed catalogue from the per-source tables already in HBM (lf_compress.h).  FREE: key = logf_i,
+// weight 1; ZEVOL: key = z_i, weight 10^(lum_i - 42).
+int build_compressed(lf_ctx* c) {
+    using namespace lf;
+    if (c->cmp.built) return LF_OK;
+    if (c->kc.variant == LF_FIXCOMP) return LF_OK;          // piece A is closed-form already
+    const int64_t N = c->N;
+    std::vector<double> key((size_t)N), wt;
+    if (N) LF_HIP(c, hipMemcpy(key.data(), c->d_a1, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    lfc::Model m{};
+    if (c->kc.variant == LF_FREE) {
+        m.kind = 0;
+        m.fc_ratio = c->kc.fc_ratio;
+        m.alpha_lo = c->kc.lims[LF_LIM_ALPHA][0];
+        m.alpha_hi = c->kc.lims[LF_LIM_ALPHA][1];
+        m.flim_lo = c->kc.lims[LF_LIM_FLIM][0];
+        m.flim_hi = c->kc.lims[LF_LIM_FLIM][1];
+    } else {
+        m.kind = 1;
+        m.L_lo = c->kc.lims[LF_LIM_LSTAR][0];
+        m.L_hi = c->kc.lims[LF_LIM_LSTAR][1];
+        for (int i = 0; i < 3; ++i) m.piv[i] = c->kc.pivots[i];
+        wt.resize((size_t)N);
+        if (N) LF_HIP(c, hipMemcpy(wt.data(), c->d_lum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < N; ++i) wt[(size_t)i] = std::pow(10.0, wt[(size_t)i] - LF_LREF);
+    }
+    lfc::Out out;
+    CompressedCat cc;
+    cc.field_ind.assign(1, 0);
+    for (int f = 0; f < c->kc.nf; ++f) {
+        const int64_t lo = c->field_ind[f], hi = c->field_ind[f + 1];
+        if (!lfc::compress_field(m, key.data() + lo, wt.empty() ? nullptr : wt.data() + lo, hi - lo, out)) {
+            c->err = "compress: the catalogue of field " + std::to_string(f) + " cannot be compressed to the error bound "
+                     "(non-finite coordinate, or a prior box the bins cannot resolve)";
+            return LF_ERR_ARG;
+        }
+        cc.field_ind.push_back((int64_t)out.node.size());
+    }
+    cc.n = (int64_t)out.node.size();
+    cc.nbins = out.nbins;
+    cc.bound = out.bound;
+    std::vector<double> lumc((size_t)cc.n, c->kc.variant == LF_ZEVOL ? LF_LREF : 0.0), U((size_t)cc.n);
+    for (int64_t i = 0; i < cc.n; ++i)
+        U[(size_t)i] = c->kc.variant == LF_FREE ? std::pow(10.0, out.node[(size_t)i] - LF_FREF) : out.node[(size_t)i] * out.node[(size_t)i];
+    int rc;
+    if ((rc = upload(c, &cc.d_lum, lumc.data(), (size_t)cc.n)) != LF_OK) return rc;
+    if ((rc = upload(c, &cc.d_a1, out.node.data(), (size_t)cc.n)) != LF_OK) return rc;
+    if ((rc = upload(c, &cc.d_U, U.data(), (size_t)cc.n)) != LF_OK) return rc;
+    if ((rc = upload(c, &cc.d_W, out.weight.data(), (size_t)cc.n)) != LF_OK) return rc;
+    cc.built = true;
+    c->cmp = cc;
     return LF_OK;
 }
 
@@ -286,6 +429,8 @@ void free_ctx(lf_ctx* c) {
         hipFree(kv.second.d_len);
         hipFree(kv.second.d_field);
     }
+    free_cmp(c->cmp);
+    if (c->d_partR) hipFree(c->d_partR);
     double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4,
                       c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
     for (double* b : bufs)
@@ -621,6 +766,15 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
         c->opt_taper = value != 0;
         return LF_OK;
     }
+    if (std::strcmp(key, "compress") == 0) {
+        if (value != 0) {
+            hipSetDevice(c->device);
+            const int rc = build_compressed(c);
+            if (rc != LF_OK) return rc;
+        }
+        c->opt_compress = value != 0;
+        return LF_OK;
+    }
     if (std::strcmp(key, "skip_grid") == 0) {
         c->opt_skip_grid = value != 0;
         return LF_OK;
@@ -635,6 +789,32 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     }
     c->err = std::string("unknown option ") + key;
     return LF_ERR_ARG;
+}
+
+int64_t lf_compress_keys(int kind, const double* params, const double* key, const double* wt, int64_t n,
+                         double* node, double* weight, int64_t cap, double* bound) {
+    if (!params || (!key && n > 0) || n < 0 || (kind != 0 && kind != 1)) return LF_ERR_ARG;
+    lfc::Model m{};
+    m.kind = kind;
+    if (kind == 0) {
+        m.fc_ratio = params[0];
+        m.alpha_lo = params[1];
+        m.alpha_hi = params[2];
+        m.flim_lo = params[3];
+        m.flim_hi = params[4];
+    } else {
+        m.L_lo = params[0];
+        m.L_hi = params[1];
+        for (int i = 0; i < 3; ++i) m.piv[i] = params[2 + i];
+    }
+    lfc::Out out;
+    if (!lfc::compress_field(m, key, wt, n, out)) return LF_ERR_ARG;
+    if (bound) *bound = out.bound;
+    const int64_t cnt = (int64_t)out.node.size();
+    if (cnt > cap || !node || !weight) return cnt;
+    std::copy(out.node.begin(), out.node.end(), node);
+    std::copy(out.weight.begin(), out.weight.end(), weight);
+    return cnt;
 }
 
 /* ---------------------------------------------------------------------------------------------

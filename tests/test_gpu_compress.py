@@ -1,0 +1,150 @@
+"""The compressed-catalogue option (lf_set_option "compress", csrc/lf_compress.h) against the same references
+as the direct path: golden vectors recorded from the reference, the oracle on seeded inputs, the reference's
+own numbers at BASELINE sizes, and the direct path itself.  Same stated tolerance, RTOL = 1e-12; the measured
+differences (printed) are at the 1e-15 level.  Needs a real MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from lf_testlib import O, compare_rows, make_inputs, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
+               if os.path.basename(f).split("_")[0] in ("free", "zevol"))
+RTOL = 1e-12
+
+
+def ctx_of(inp, compress=True):
+    from lumfuncmcmc_amd.capi import LFContext
+    ctx = LFContext(inp, device=0)
+    if compress:
+        ctx.set_option("compress", 1)
+    return ctx
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_vectors_compressed(case):
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    inp = O.inputs_from_golden(g, case.split("_")[0])
+    ctx = ctx_of(inp)
+    th = g["theta"]
+    got = ctx.lnprob_batch(th)
+    w = compare_rows(got, g["lnprob"], inp, th, RTOL)
+    A, B = ctx.lnprob_pieces(th)
+    wa = compare_rows(A, g["A"], inp, th, RTOL, "A")
+    assert np.array_equal(np.isnan(A), np.isnan(g["A"]))
+    print("%s compressed: worst rel lnprob %.2e A %.2e" % (case, w, wa))
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant,n,fsa,B", [("free", 200000, False, 37), ("free", 4099, True, 64),
+                                             ("zevol", 160000, False, 37), ("zevol", 7777, True, 131)])
+def test_compressed_matches_direct_and_oracle(variant, n, fsa, B):
+    inp = make_inputs(variant, n, seed=77 + n, fix_sch_al=fsa, zslices=8 if variant == "zevol" else 0)
+    th = synth.walkers(variant, B, seed=6, fix_sch_al=fsa)
+    ctx = ctx_of(inp, compress=False)
+    direct = ctx.lnprob_batch(th)
+    dA, dB = ctx.lnprob_pieces(th)
+    ctx.set_option("compress", 1)
+    got = ctx.lnprob_batch(th)
+    A, Bp = ctx.lnprob_pieces(th)
+    assert np.array_equal(Bp, dB)                                  # the grid integral is untouched
+    relA = np.max(np.abs(A - dA) / np.abs(dA))
+    rel = np.max(np.abs(got - direct) / np.abs(direct))
+    print("%s n=%d: compressed vs direct: lnprob %.2e piece A %.2e" % (variant, n, rel, relA))
+    assert rel < 1e-13 and relA < 1e-13
+    if n <= 10000:
+        compare_rows(got, O.lnprob_batch(inp, th), inp, th, RTOL)
+    for gi in (1, 2, 4, 8):                                        # every instantiated geometry
+        ctx.set_option("geometry", gi)
+        np.testing.assert_allclose(ctx.lnprob_batch(th), got, rtol=1e-14)
+    ctx.set_option("geometry", -1)
+    ctx.set_option("compress", 0)                                  # and off again: the direct bits
+    assert np.array_equal(ctx.lnprob_batch(th), direct)
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["free", "zevol"])
+def test_walkers_that_need_the_per_source_checks_are_summed_over_the_real_catalogue(variant):
+    """Rows of the underflow zone (App. B-5) and of the full prior: the compressed path must return the direct
+    path's value for them - -inf where a source's product underflows, the careful sum elsewhere."""
+    inp = make_inputs(variant, 20000, seed=31, zslices=8 if variant == "zevol" else 0)
+    th = np.concatenate([synth.walkers(variant, 24, seed=8), _underflow_rows(variant, 40)])
+    ctx = ctx_of(inp, compress=False)
+    ctx.set_option("geometry", 1)                                  # the chunk size the rescue workgroups use
+    direct = ctx.lnprob_batch(th)
+    ctx.set_option("geometry", -1)
+    ctx.set_option("compress", 1)
+    got = ctx.lnprob_batch(th)
+    ref = O.lnprob_batch(inp, th)
+    compare_rows(got, ref, inp, th, RTOL)
+    assert np.array_equal(np.isinf(got), np.isinf(direct))
+    fin = np.isfinite(direct)
+    np.testing.assert_allclose(got[fin], direct[fin], rtol=1e-13)
+    nslow = int(np.sum(np.isinf(direct)))
+    print("%s: %d of %d rows -inf, identical pattern" % (variant, nslow, len(th)))
+    assert nslow > 0
+    ctx.close()
+
+
+def _underflow_rows(variant, n):
+    """theta rows inside the prior whose brightest sources drive exp(-10^(lum - L*)) towards underflow"""
+    rng = np.random.default_rng(99)
+    th = synth.walkers(variant, n, seed=10)
+    if variant == "zevol":
+        th[:, 0:3] = rng.uniform(40.05, 41.2, (n, 3))
+    else:
+        th[:, 0] = rng.uniform(40.05, 41.2, n)
+    return th
+
+
+@pytest.mark.parametrize("name", ["e2e_free_n100000", "e2e_free_n1000000", "e2e_zevol_n800000"])
+def test_end_to_end_against_the_reference_compressed(name):
+    """BASELINE sizes, the reference's own lnprob as the oracle (see test_gpu_parity), compressed catalogue on."""
+    from lumfuncmcmc_amd.model import LumFuncMCMC, LumFuncMCMCz
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    variant, n = str(g["variant"]), int(g["n"])
+    cat = synth.catalogue(n, seed=int(g["seed"]), zslices=int(g["zslices"]))
+    fi = cat["field_ind"]
+    kw = dict(lum=synth.split_fields(cat["lum"], fi), lum_e=synth.split_fields(cat["lum_e"], fi),
+              Flim=list(synth.FLIM), alpha=synth.ALPHA_C, Omega_0=list(synth.OMEGA_0), sch_al=synth.SCH_AL,
+              sch_al_lims=synth.SCH_AL_LIMS, Lstar=synth.LSTAR, Lstar_lims=synth.LSTAR_LIMS,
+              phistar=synth.PHISTAR, phistar_lims=synth.PHISTAR_LIMS, Lc=synth.LC, Lh=synth.LH, nwalkers=32,
+              nsteps=10, min_comp_frac=0.0, field_ind=fi)
+    zs = synth.split_fields(cat["z"], fi)
+    if variant == "zevol":
+        o = LumFuncMCMCz(zs, **kw)
+    else:
+        o = LumFuncMCMC(zs, Flim_lims=synth.FLIM_LIMS, alpha_lims=synth.ALPHA_LIMS, **kw)
+    o.context().set_option("compress", 1)
+    got = o.lnprob(g["theta"])
+    ref = g["lnprob"]
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    rel = np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])
+    print("%s compressed: worst rel vs the reference %.2e" % (name, rel.max()))
+    assert rel.max() < RTOL
+    o.close()
+
+
+def test_device_sampler_on_the_compressed_catalogue():
+    """The device-resident sampler goes through the same enqueue: its recorded lnprob must be the direct
+    path's lnprob of the recorded positions."""
+    from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
+    inp = make_inputs("free", 50000, seed=41)
+    ctx = ctx_of(inp)
+    W = 32
+    p0 = synth.walkers("free", W, seed=11)
+    ds = DeviceEnsembleSampler(ctx, W, seed=3, capacity=12)
+    ds.run_mcmc(p0, 12)
+    chain, lnp = ds.chain, ds.lnprobability
+    ds.close()
+    ctx.set_option("compress", 0)
+    last = ctx.lnprob_batch(chain[:, -1, :])
+    np.testing.assert_allclose(lnp[:, -1], last, rtol=1e-13)
+    assert 0.05 < ds.acceptance_fraction.mean() <= 1.0
+    ctx.close()

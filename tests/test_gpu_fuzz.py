@@ -40,7 +40,7 @@ def test_random_configuration(seed):
         th[2, -1] = np.nan
     ref = O.lnprob_batch(inp, th)
     ctx = LFContext(inp)
-    for gi in (-1, int(rng.integers(0, 8))):
+    for gi in (-1, int(rng.integers(0, 9))):
         ctx.set_option("geometry", gi)
         got = ctx.lnprob_batch(th)
         compare_rows(got, ref, inp, th, RTOL, "seed %d geo %d" % (seed, gi))

@@ -153,7 +153,7 @@ def test_chunking_does_not_change_results():
     ctx = ctx_of(inp)
     base = ctx.lnprob_batch(th)
     assert np.array_equal(base, ctx.lnprob_batch(th))            # bitwise reproducible
-    for gi in (0, 1, 2, 3, 4, 5, 6, 7, -1):
+    for gi in (0, 1, 2, 3, 4, 5, 6, 7, 8, -1):
         ctx.set_option("geometry", gi)
         np.testing.assert_allclose(ctx.lnprob_batch(th), base, rtol=1e-14)
     ctx.close()
