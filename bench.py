@@ -127,12 +127,19 @@ def main():
     ap.add_argument("--geometry", type=int, default=-1)
     ap.add_argument("--walker-tile", type=int, default=0)
     ap.add_argument("--no-taper", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")
     ap.add_argument("--default-stream", action="store_true", help="launch on the legacy default stream instead of a side stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
     args = ap.parse_args()
+    # stdout carries exactly ONE line (the JSON): libraries that print there (RCCL's version banner at
+    # communicator init does) are sent to stderr from here on
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -148,7 +155,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_collective:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -173,7 +183,7 @@ def main():
     nblk = 8
     theta_all = synth.walkers(args.variant, half * world * nblk, seed=1).reshape(nblk, half * world, ndim)
     blocks = [torch.from_numpy(theta_all[i]).to(dev) for i in range(nblk)]
-    sharded = ShardedLnProb(ctx.lnprob_torch, ndim, dev)
+    sharded = ShardedLnProb(ctx.lnprob_torch, ndim, dev, force_collective=args.force_collective)
 
     def step(i):
         a = sharded.evaluate_tensor(blocks[(2 * i) % nblk])
@@ -181,7 +191,7 @@ def main():
         return a, b
 
     def fence():
-        if world > 1:
+        if world > 1 or args.force_collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,7 +212,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.set_profiling(0)
     kt = ctx.kernel_times()
-    if world > 1:
+    if world > 1 or args.force_collective:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -278,8 +288,8 @@ def main():
                 res["cpu_baseline_allcores"] = cpu_baseline_allcores(model, theta_all[0], nthr)
             except Exception as e:            # the extra figure must never cost the bench line
                 res["cpu_baseline_allcores"] = {"error": str(e)}
-        print(json.dumps(res))
-    if world > 1:
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

@@ -25,7 +25,7 @@ class ShardedLnProb(object):
     product this is LFContext.lnprob_torch.  Every rank must call with the same block.
     """
 
-    def __init__(self, local_eval, ndim, device, group=None):
+    def __init__(self, local_eval, ndim, device, group=None, force_collective=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -33,6 +33,9 @@ class ShardedLnProb(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._buffers = {}
+        # a one-rank group normally skips the collective; force_collective keeps it (one-GPU rehearsal of the
+        # RCCL path: same calls, same stream ordering, a degenerate gather)
+        self._collective = self.world > 1 or (force_collective and dist.is_initialized())
         # RCCL/NCCL gathers in place (the input is the rank's slice of the output); other backends
         # (gloo in the CPU tests and one-GPU rehearsals) get a separate input buffer
         self._inplace = dist.is_initialized() and dist.get_backend(group) == "nccl"
@@ -48,7 +51,7 @@ class ShardedLnProb(object):
         no staging copy, no allocation per call)."""
         torch, dist = self.torch, self.dist
         B = theta.shape[0]
-        if self.world == 1:
+        if not self._collective:
             return self.local_eval(theta)
         bounds, per = slice_bounds(B, self.world)
         lo, hi = bounds[self.rank]

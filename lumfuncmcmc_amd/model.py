@@ -30,6 +30,7 @@ class _Base(object):
 
     _logger_name = 'lumfuncmcmc'
     device = 0
+    compress = False               # True: piece A from the compressed catalogue (csrc/lf_compress.h), opt-in
 
     # ------------------------------------------------------------------ setup (host, once)
     def _common_init(self, z, flux, flux_e, lum, lum_e):
@@ -148,6 +149,8 @@ class _Base(object):
                 self._ctx.close()
             self._ctx = LFContext(self.kernel_inputs(), device=self.device,
                                   max_batch=max(8, getattr(self, "nwalkers", 100) // 2))
+            if self.compress:
+                self._ctx.set_option("compress", 1)
             self._ctx_key = key
         return self._ctx
 
@@ -274,9 +277,10 @@ class LumFuncMCMC(_Base):
                  nboot=100, sch_al=-1.6, sch_al_lims=[-3.0, 1.0], Lstar=42.5, Lstar_lims=[40.0, 45.0],
                  phistar=-3.0, phistar_lims=[-8.0, 5.0], Lc=40.0, Lh=46.0, nwalkers=100, nsteps=1000,
                  fix_sch_al=False, fcmin=0.1, fix_comp=False, min_comp_frac=0.5,
-                 field_names=None, field_ind=None, diff_rand=True, device=0):
+                 field_names=None, field_ind=None, diff_rand=True, device=0, compress=False):
         self._common_init(z, flux, flux_e, lum, lum_e)
         self.device = device
+        self.compress = bool(compress)
         self.fcmin, self.min_comp_frac = fcmin, min_comp_frac
         self.Flim, self.Flim_lims = Flim, Flim_lims
         self.fields, self.nfields = field_names, len(self.Flim)
@@ -410,9 +414,10 @@ class LumFuncMCMCz(_Base):
                  nboot=100, sch_al=-1.6, sch_al_lims=[-3.0, 1.0], Lstar=42.5, Lstar_lims=[41.0, 45.0],
                  phistar=-3.0, phistar_lims=[-8.0, 5.0], Lc=40.0, Lh=46.0, nwalkers=100, nsteps=1000,
                  fcmin=0.1, min_comp_frac=0.5, field_names=None,
-                 field_ind=None, z1=1.20, z2=1.53, z3=1.86, fix_sch_al=False, device=0):
+                 field_ind=None, z1=1.20, z2=1.53, z3=1.86, fix_sch_al=False, device=0, compress=False):
         self._common_init(z, flux, flux_e, lum, lum_e)
         self.device = device
+        self.compress = bool(compress)
         self.z1, self.z2, self.z3 = z1, z2, z3
         self.fcmin, self.min_comp_frac = fcmin, min_comp_frac
         self.Flim = Flim
