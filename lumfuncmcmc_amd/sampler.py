@@ -150,7 +150,7 @@ class DeviceEnsembleSampler(object):
             self._started = True
         self.ctx._check(lib.lf_sampler_run(self._h, int(nsteps), None))
 
-    def enqueue_sharded(self, pos, nsteps, group=None, lnprob0=None):
+    def enqueue_sharded(self, pos, nsteps, group=None, lnprob0=None, force_collective=False):
         """The same chain with the walkers of every half-step sharded over the ranks of a
         torch.distributed group (one process per GPU): propose everywhere, evaluate the local slice,
         all-gather the slice's lnprob (RCCL, in stream order), accept everywhere."""
@@ -170,8 +170,10 @@ class DeviceEnsembleSampler(object):
         lo, hi = bounds[rank]
         dev = torch.device("cuda", self.ctx.device)
         buf = torch.full((per * world,), float("-inf"), dtype=torch.float64, device=dev)
-        inplace = world > 1 and dist.get_backend(group) == "nccl"      # RCCL gathers in place
-        sep = None if (inplace or world == 1) else torch.full((per,), float("-inf"), dtype=torch.float64, device=dev)
+        # force_collective: keep the all-gather with a one-rank group (one-GPU rehearsal of the RCCL path)
+        collective = world > 1 or (force_collective and dist.is_initialized())
+        inplace = collective and dist.get_backend(group) == "nccl"      # RCCL gathers in place
+        sep = None if (inplace or not collective) else torch.full((per,), float("-inf"), dtype=torch.float64, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         for _ in range(int(nsteps)):
             for h in (0, 1):
@@ -179,7 +181,7 @@ class DeviceEnsembleSampler(object):
                 mine = buf[rank * per:(rank + 1) * per] if sep is None else sep
                 self.ctx._check(lib.lf_sampler_half_eval(self._h, h, lo, hi, ct.c_void_p(mine.data_ptr() - lo * 8),
                                                          ct.c_void_p(stream)))
-                if world > 1:
+                if collective:
                     if not inplace:
                         torch.cuda.current_stream(dev).synchronize()    # gloo (rehearsal) does not order with our launches
                     dist.all_gather_into_tensor(buf, mine, group=group)
