@@ -134,6 +134,9 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * bin sum, over the whole prior box, is below 1e-16 (csrc/lf_compress.h).  lnprob then costs the grid integral
  * plus a few hundred terms, whatever N is.  Walkers that need the per-source underflow checks are still summed
  * over the real catalogue.  Built at the first call with value 1 (returns LF_ERR_ARG if the bound cannot be met).
+ * "graph": 1 lets lf_sampler_run replay one captured hipGraph per ensemble step instead of six launches (same
+ * kernels, same random numbers, same chain; the step index then lives in device memory); 0 (default) = plain
+ * launches - on ROCm 7.0 the replay gains <= 5 % and shows a sporadic ~30 ms stall, see DESIGN.md.
  * One key changes what is computed: "skip_grid" = 1 leaves the expected-count integral (piece B) out
  * of lnprob - for source-sharded ranks other than the first, whose results are summed. */
 int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);

@@ -130,6 +130,11 @@ struct StepArgs {
     const double* pos;           // [W][ndim] current positions
     double* prop;                // [halfW][ndim] proposals of the active half
     double* zz;                  // [halfW] stretch factors
+    // replayable form (hipGraph): the step index is read from device memory, step = *d_step - step_off.
+    // The counter is bumped by lf_main of half 0, i.e. after the half-0 prepare has read it (step_off = 0)
+    // and before everything else of the step does (step_off = 1).
+    const unsigned long long* d_step;
+    int step_off;
 };
 struct AcceptArgs {
     int enabled;
@@ -143,6 +148,7 @@ struct AcceptArgs {
     long long* nacc;             // [W]
     double* chain;               // [W][cap][ndim]
     double* chain_lnp;           // [W][cap]
+    const unsigned long long* d_step;   // replayable form: step = t = *d_step - 1 (see StepArgs)
 };
 
 __device__ __forceinline__ void philox4x32(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     //   y = x_j - (x_j - x_k) z,   z = ((a - 1) u + 1)^2 / a,   j uniform in the other half
     if (sp.enabled) {
         unsigned int rr[4];
-        sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
+        const unsigned long long step = sp.d_step ? *sp.d_step - (unsigned long long)sp.step_off : sp.step;
+        sampler_draw(step, sp.half, w, 0, sp.seed, rr);
         const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
         const int j = (1 - sp.half) * sp.halfW + (int)(((unsigned long long)rr[2] * (unsigned long long)sp.halfW) >> 32);
         const int k = sp.half * sp.halfW + w;
@@ -689,6 +696,7 @@ struct Rescue {
     const int* wstat;
     double* partR;
     int nchD, nresc;
+    unsigned long long* bump;   // sampler step counter to advance (graph replay, half 0 only), or NULL
 };
 
 template <int VARIANT, int ST, int TW, int TWB, bool CMP>
@@ -700,6 +708,7 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
     __shared__ MathTables tab;
     __shared__ double red[(TW > TWB ? TW : TWB) * BLOCK];
     load_tables(&tab);
+    if (rs.bump && blockIdx.x == 0 && threadIdx.x == 0) *rs.bump += 1ull;   // no reader of the counter in this launch
     __syncthreads();
     int id = blockIdx.x;
     if (id < nblkB) {
@@ -746,20 +755,22 @@ __device__ __forceinline__ void accept_walker(const AcceptArgs& ap, int w, doubl
     const int k = ap.half * ap.halfW + w;
     const double oldlp = ap.lnp[k];
     unsigned int rr[4];
-    sampler_draw(ap.step, ap.half, w, 1, ap.seed, rr);
+    const unsigned long long step = ap.d_step ? *ap.d_step - 1ull : ap.step;
+    const long long t = ap.d_step ? (long long)step : ap.t;
+    sampler_draw(step, ap.half, w, 1, ap.seed, rr);
     const double lnq = (ap.ndim - 1.0) * log(ap.zz[w]) + newlp - oldlp;
     const bool acc = (log(u53(rr[0], rr[1])) < lnq) && (newlp > -__builtin_huge_val());
     if (lane < ap.ndim) {
         const double v = acc ? ap.prop[(size_t)w * ap.ndim + lane] : ap.pos[(size_t)k * ap.ndim + lane];
         if (acc) ap.pos[(size_t)k * ap.ndim + lane] = v;
-        ap.chain[((size_t)k * ap.cap + ap.t) * ap.ndim + lane] = v;
+        ap.chain[((size_t)k * ap.cap + t) * ap.ndim + lane] = v;
     }
     if (lane == 0) {
         if (acc) {
             ap.lnp[k] = newlp;
             ap.nacc[k] += 1;
         }
-        ap.chain_lnp[(size_t)k * ap.cap + ap.t] = acc ? newlp : oldlp;
+        ap.chain_lnp[(size_t)k * ap.cap + t] = acc ? newlp : oldlp;
     }
 }
 
@@ -771,7 +782,7 @@ __global__ __launch_bounds__(64) void lf_propose(StepArgs sp) {
     const int w = gt >> 3, f = gt & 7;
     if (w >= sp.halfW) return;
     unsigned int rr[4];
-    sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
+    sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);       // (the sharded form is never graph-captured)
     const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
     const int j = (1 - sp.half) * sp.halfW + (int)(((unsigned long long)rr[2] * (unsigned long long)sp.halfW) >> 32);
     const int k = sp.half * sp.halfW + w;
@@ -779,6 +790,9 @@ __global__ __launch_bounds__(64) void lf_propose(StepArgs sp) {
         sp.prop[(size_t)w * sp.ndim + i] = stretch_point(sp.pos[(size_t)j * sp.ndim + i], sp.pos[(size_t)k * sp.ndim + i], z);
     if (f == 0) sp.zz[w] = z;
 }
+
+// sets the device-side step counter of a sampler before a run of graph replays
+__global__ void lf_setctr(unsigned long long* p, unsigned long long v) { *p = v; }
 
 __global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __restrict__ newlp) {
     const int w = blockIdx.x;

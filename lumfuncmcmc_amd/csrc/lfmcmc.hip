@@ -61,6 +61,8 @@ struct lf_ctx {
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     int64_t opt_taper = 1;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers
     int64_t opt_skip_grid = 0;          // 1: leave piece B out (source-sharded ranks other than the first)
+    int64_t opt_graph = 0;              // 1: lf_sampler_run replays a captured hipGraph of one ensemble step (opt-in)
+    uint64_t generation = 0;            // bumped whenever captured launch arguments go stale (workspace, options)
     int64_t opt_compress = 0;           // 1: piece A from the compressed catalogue (FREE, ZEVOL)
     CompressedCat cmp;
     double* d_partR = nullptr;          // rescue partials [B][chunks of the real catalogue]
@@ -148,6 +150,7 @@ int pick_geometry(const lf_ctx* c, int B) {
 int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t partR = 0) {
     if (Bpad > c->cap_B) {
         int nb = std::max(Bpad, c->cap_B * 2);
+        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
         hipFree(c->d_theta); hipFree(c->d_out); hipFree(c->d_outA); hipFree(c->d_outB);
         hipFree(c->d_wrec); hipFree(c->d_wstat); hipFree(c->d_wmode); hipFree(c->d_wbase);
@@ -167,6 +170,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         c->cap_B = nb;
     }
     if (partA > c->cap_partA) {
+        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
         hipFree(c->d_partA);
         c->cap_partA = 0;
@@ -174,6 +178,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         c->cap_partA = partA;
     }
     if (partR > c->cap_partR) {
+        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
         hipFree(c->d_partR);
         c->cap_partR = 0;
@@ -181,6 +186,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         c->cap_partR = partR;
     }
     if (partB > c->cap_partB) {
+        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
         hipFree(c->d_partB);
         c->cap_partB = 0;
@@ -237,22 +243,23 @@ void launch_main_cmp(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, i
 
 template <int VARIANT>
 void launch_main(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int nblkB, hipStream_t s,
-                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB) {
+                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB, const lf::Rescue& rs) {
     switch (gi) {
-        case 0: launch_geo<VARIANT, 0>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 1: launch_geo<VARIANT, 1>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 2: launch_geo<VARIANT, 2>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 3: launch_geo<VARIANT, 3>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 4: launch_geo<VARIANT, 4>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 5: launch_geo<VARIANT, 5>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 6: launch_geo<VARIANT, 6>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        case 7: launch_geo<VARIANT, 7>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-        default: launch_geo<VARIANT, 8>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+        case 0: launch_geo<VARIANT, 0>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 1: launch_geo<VARIANT, 1>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 2: launch_geo<VARIANT, 2>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 3: launch_geo<VARIANT, 3>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 4: launch_geo<VARIANT, 4>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 5: launch_geo<VARIANT, 5>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 6: launch_geo<VARIANT, 6>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        case 7: launch_geo<VARIANT, 7>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+        default: launch_geo<VARIANT, 8>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
     }
 }
 
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
-            hipStream_t s, const lf::StepArgs* step = nullptr, const lf::AcceptArgs* accept = nullptr) {
+            hipStream_t s, const lf::StepArgs* step = nullptr, const lf::AcceptArgs* accept = nullptr,
+            unsigned long long* bump = nullptr) {
     using namespace lf;
     StepArgs sp{};
     AcceptArgs ap{};
@@ -278,6 +285,10 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + BLOCK - 1) / BLOCK;
     rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * nchD);
     if (rc != LF_OK) return rc;
+    if (bump && nchB * (int64_t)B + nchA <= 0) {
+        c->err = "internal: a replayable step needs a non-empty lf_main launch";
+        return LF_ERR_ARG;
+    }
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
@@ -291,6 +302,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field};
     SrcArrays sa = sd;
     Rescue rs{};
+    rs.bump = bump;
     if (cmp) {
         sa = SrcArrays{c->cmp.d_lum, c->cmp.d_a1, c->cmp.d_lum, c->cmp.d_U, c->cmp.d_W, ct->d_start, ct->d_len, ct->d_field};
         rs.sd = sd;
@@ -334,9 +346,9 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
                 if (c->kc.variant == LF_FREE) launch_main_cmp<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
                 else launch_main_cmp<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
             } else switch (c->kc.variant) {
-                case LF_FREE: launch_main<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-                case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB); break;
-                default: launch_main<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB);
+                case LF_FREE: launch_main<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+                case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
+                default: launch_main<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
             }
         }
     }
@@ -754,6 +766,11 @@ int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
 
 int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return LF_ERR_ARG;
+    ++c->generation;                    // captured sampler graphs are rebuilt after any option change
+    if (std::strcmp(key, "graph") == 0) {
+        c->opt_graph = value != 0;
+        return LF_OK;
+    }
     if (std::strcmp(key, "geometry") == 0) {
         if (value < -1 || value >= NGEO) {
             c->err = "geometry must be -1 (auto) or an index below " + std::to_string(NGEO);
@@ -830,6 +847,12 @@ struct lf_sampler {
     double *d_chain = nullptr, *d_chain_lnp = nullptr;
     long long* d_nacc = nullptr;
     bool started = false;
+    // replayable ensemble step (hipGraph): device-side step counter, the instantiated graph, and the
+    // context generation / stream it was captured for
+    unsigned long long* d_ctr = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    uint64_t graph_gen = 0;
 };
 
 lf_sampler* lf_sampler_create(lf_ctx* c, int nwalkers, double a, uint64_t seed, int64_t capacity_steps) {
@@ -853,7 +876,8 @@ lf_sampler* lf_sampler_create(lf_ctx* c, int nwalkers, double a, uint64_t seed, 
               hipMalloc((void**)&sm->d_newlp, W * 8) == hipSuccess &&
               hipMalloc((void**)&sm->d_chain, W * cap * nd * 8) == hipSuccess &&
               hipMalloc((void**)&sm->d_chain_lnp, W * cap * 8) == hipSuccess &&
-              hipMalloc((void**)&sm->d_nacc, W * sizeof(long long)) == hipSuccess;
+              hipMalloc((void**)&sm->d_nacc, W * sizeof(long long)) == hipSuccess &&
+              hipMalloc((void**)&sm->d_ctr, sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
         c->err = "lf_sampler_create: device allocation failed";
         lf_sampler_destroy(sm);
@@ -869,7 +893,9 @@ void lf_sampler_destroy(lf_sampler* sm) {
         hipDeviceSynchronize();
     }
     hipFree(sm->d_pos); hipFree(sm->d_lnp); hipFree(sm->d_prop); hipFree(sm->d_zz); hipFree(sm->d_newlp);
-    hipFree(sm->d_chain); hipFree(sm->d_chain_lnp); hipFree(sm->d_nacc);
+    hipFree(sm->d_chain); hipFree(sm->d_chain_lnp); hipFree(sm->d_nacc); hipFree(sm->d_ctr);
+    if (sm->gexec) hipGraphExecDestroy(sm->gexec);
+    if (sm->graph) hipGraphDestroy(sm->graph);
     delete sm;
 }
 
@@ -907,6 +933,59 @@ int lf_sampler_run(lf_sampler* sm, int64_t nsteps, void* hip_stream) {
     LF_HIP(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const int halfW = sm->W / 2;
+    // A step is six small launches; at small N (or with the compressed catalogue) it is bound by launch
+    // latency.  Capture ONE step as a hipGraph (step index read from device memory, see StepArgs) and replay it.
+    if (c->opt_graph && c->profiling == 0 && nsteps >= 2 && !(c->N == 0 && c->opt_skip_grid)) {
+        if (!sm->gexec || sm->graph_gen != c->generation) {
+            if (sm->gexec) hipGraphExecDestroy(sm->gexec);
+            if (sm->graph) hipGraphDestroy(sm->graph);
+            sm->gexec = nullptr;
+            sm->graph = nullptr;
+            // a plain step first: sizes the workspace, fills the chunk-table cache and settles the stream
+            // hand-over, none of which may happen inside a capture
+            for (int half = 0; half < 2; ++half) {
+                lf::StepArgs sp{1, half, halfW, sm->ndim, sm->step, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz};
+                lf::AcceptArgs ap{1, half, halfW, sm->ndim, sm->step, sm->seed, (long long)sm->t, (long long)sm->cap,
+                                  sm->d_pos, sm->d_lnp, sm->d_prop, sm->d_zz, sm->d_nacc, sm->d_chain, sm->d_chain_lnp};
+                int rc = enqueue(c, nullptr, halfW, sm->d_newlp, nullptr, nullptr, s, &sp, &ap);
+                if (rc != LF_OK) return rc;
+            }
+            sm->step += 1;
+            sm->t += 1;
+            nsteps -= 1;
+            const uint64_t gen = c->generation;
+            LF_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            int rc = LF_OK;
+            for (int half = 0; half < 2 && rc == LF_OK; ++half) {
+                lf::StepArgs sp{1, half, halfW, sm->ndim, 0, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz, sm->d_ctr, half};
+                lf::AcceptArgs ap{1, half, halfW, sm->ndim, 0, sm->seed, 0, (long long)sm->cap,
+                                  sm->d_pos, sm->d_lnp, sm->d_prop, sm->d_zz, sm->d_nacc, sm->d_chain, sm->d_chain_lnp, sm->d_ctr};
+                rc = enqueue(c, nullptr, halfW, sm->d_newlp, nullptr, nullptr, s, &sp, &ap, half == 0 ? sm->d_ctr : nullptr);
+            }
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            if (rc != LF_OK) {
+                if (g) hipGraphDestroy(g);
+                return rc;
+            }
+            if (e != hipSuccess || c->generation != gen) {
+                if (g) hipGraphDestroy(g);
+                c->err = std::string("lf_sampler_run: graph capture failed: ") + hipGetErrorString(e);
+                return LF_ERR_HIP;
+            }
+            sm->graph = g;
+            LF_HIP(c, hipGraphInstantiate(&sm->gexec, sm->graph, nullptr, nullptr, 0));
+            sm->graph_gen = gen;
+        }
+        if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));   // as enqueue does
+        c->last_stream = s;
+        c->any_enqueued = true;
+        hipLaunchKernelGGL(lf::lf_setctr, dim3(1), dim3(1), 0, s, sm->d_ctr, (unsigned long long)sm->step);
+        for (int64_t it = 0; it < nsteps; ++it) LF_HIP(c, hipGraphLaunch(sm->gexec, s));
+        sm->step += (uint64_t)nsteps;
+        sm->t += nsteps;
+        return LF_OK;
+    }
     for (int64_t it = 0; it < nsteps; ++it) {
         for (int half = 0; half < 2; ++half) {
             lf::StepArgs sp{1, half, halfW, sm->ndim, sm->step, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz};

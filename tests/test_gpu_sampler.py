@@ -95,6 +95,37 @@ def test_device_chain_equals_host_replay(variant, n, W):
     ds.close(); ds2.close(); ctx.close()
 
 
+@pytest.mark.parametrize("variant,compress", [("free", 0), ("free", 1), ("zevol", 0)])
+def test_graph_replay_gives_the_same_chain_as_plain_launches(variant, compress):
+    """lf_sampler_run replays one captured hipGraph per ensemble step (step index read from device memory);
+    the chain must be the plain launches' chain bit for bit - across several run calls, a walker-count that
+    is not a tile multiple, an option change (re-capture) and a workspace growth in between."""
+    from lumfuncmcmc_amd.capi import LFContext
+    from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
+    inp = make_inputs(variant, 5000, seed=61)
+    ctx = LFContext(inp, max_batch=8)
+    if compress:
+        ctx.set_option("compress", 1)
+    W, nsteps, seed = 44, 31, 77
+    pos = synth.walkers(variant, W, seed=62)
+    ctx.set_option("graph", 0)
+    plain = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
+    plain.run_mcmc(pos, nsteps)
+    ctx.set_option("graph", 1)
+    g = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
+    g.run_mcmc(pos, 7)
+    g.run_mcmc(None, 1)                                        # a single step takes the plain path
+    ctx.lnprob_batch(synth.walkers(variant, 700, seed=63))     # grows the workspace: the captured pointers are stale
+    g.run_mcmc(None, 9)
+    ctx.set_option("geometry", 1)                              # forces a re-capture; same chunking for 5000 sources
+    ctx.set_option("geometry", -1)
+    g.run_mcmc(None, 14)
+    assert np.array_equal(g.chain, plain.chain)
+    assert np.array_equal(g.lnprobability, plain.lnprobability)
+    assert np.array_equal(g.naccepted, plain.naccepted)
+    plain.close(); g.close(); ctx.close()
+
+
 def test_device_sampler_recovers_a_posterior():
     """End to end on the likelihood itself: sample the fixed-completeness posterior of a catalogue drawn
     from a known Schechter function and check that the chain concentrates near the truth."""
