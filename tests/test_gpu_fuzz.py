@@ -44,4 +44,40 @@ def test_random_configuration(seed):
         ctx.set_option("geometry", gi)
         got = ctx.lnprob_batch(th)
         compare_rows(got, ref, inp, th, RTOL, "seed %d geo %d" % (seed, gi))
+    # the compressed catalogue on the same ragged shapes (small fields stay uncompressed, n = 4500 does not)
+    ctx.set_option("geometry", -1)
+    ctx.set_option("compress", 1)
+    compare_rows(ctx.lnprob_batch(th), ref, inp, th, RTOL, "seed %d compressed" % seed)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_large_catalogue_compressed(seed):
+    """Catalogues big enough for every bin to be compressed, with skewed source distributions: compressed
+    against direct (the oracle is too slow at these sizes; direct is pinned to it above)."""
+    from lumfuncmcmc_amd.capi import LFContext
+    rng = np.random.default_rng(2000 + seed)
+    variant = ("free", "zevol")[seed % 2]
+    n = int(rng.integers(30000, 120000))
+    nf = int(rng.integers(1, 9))
+    inp = make_inputs(variant, n, seed=seed, nf=nf, fix_sch_al=bool(seed & 2), S=int(rng.integers(8, 30)),
+                      zslices=(8 if variant == "zevol" and nf == 5 else 0),
+                      pivots=(1.18, 1.36, 1.54) if seed % 3 == 0 else (1.20, 1.53, 1.86))
+    if variant == "free":
+        # steep number counts: most sources near the faint end, a bright tail
+        lum = inp["lum"]
+        inp["lum"] = np.minimum(lum.min() + rng.exponential(0.25, n), 43.5)
+        inp["lum"][0] = lum.min()                     # the grid's lower edge stays where make_inputs put it
+    B = int(rng.integers(20, 90))
+    th = synth.walkers(variant, B, seed=seed + 17, fix_sch_al=bool(seed & 2), nf=nf)
+    th[0, 0] = 40.3                                   # underflow zone: rescue workgroups
+    ctx = LFContext(inp)
+    direct = ctx.lnprob_batch(th)
+    ctx.set_option("compress", 1)
+    got = ctx.lnprob_batch(th)
+    assert np.array_equal(np.isinf(got), np.isinf(direct)) and not np.isnan(got).any()
+    fin = np.isfinite(direct)
+    rel = np.max(np.abs(got[fin] - direct[fin]) / np.abs(direct[fin]))
+    print("seed %d %s n=%d nf=%d: compressed vs direct %.2e" % (seed, variant, n, nf, rel))
+    assert rel < 1e-13
     ctx.close()
