@@ -126,7 +126,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--geometry", type=int, default=-1)
     ap.add_argument("--walker-tile", type=int, default=0)
-    ap.add_argument("--no-taper", action="store_true")
+    ap.add_argument("--no-taper", action="store_true", help="(default) single pass over the catalogue")
+    ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")
@@ -175,6 +176,8 @@ def main():
         ctx.set_option("walker_tile", args.walker_tile)
     if args.no_taper:
         ctx.set_option("taper", 0)
+    if args.taper:
+        ctx.set_option("taper", 1)
     if args.compress:
         ctx.set_option("compress", 1)
     ndim = ctx.ndim

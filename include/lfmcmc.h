@@ -126,8 +126,9 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
 /* Tuning knobs (performance only, never results beyond summation order):
  * key "geometry": index of the launch geometry (sources per lane x walkers per workgroup),
  * -1 = chosen from N and B; "walker_tile": walkers per workgroup, 0 = the geometry's;
- * "taper": 1 (default) gives the last ~B/8 walkers quarter-size tiles, dispatched last, so that the
- * launch drains evenly (bitwise neutral: a tile only decides which workgroup owns a (chunk, walker) sum).
+ * "taper": 1 gives the last ~B/8 walkers quarter-size tiles, dispatched last, so that the launch drains evenly
+ * (bitwise neutral: a tile only decides which workgroup owns a (chunk, walker) sum); +1 % at N = 1e6 but the tail
+ * tiles read the catalogue a second time (L2 -> fabric traffic 37 MB instead of 21 MB per launch): off by default.
  * "compress": 1 = take piece A from the COMPRESSED CATALOGUE (FREE, ZEVOL; off by default): the ~N sources of a
  * field are replaced by K = 16 weighted pseudo-sources per bin of the one coordinate the walker-dependent factor
  * of a term depends on (log flux; redshift), with bins refined until the bound on the relative error of every

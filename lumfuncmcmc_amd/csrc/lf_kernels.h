@@ -612,9 +612,14 @@ __device__ __forceinline__ double field_sum(const KConst& kc, const double* __re
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const double num = fma(alphaC, a3, lF[f]);                    // alpha_C (logf - lF)
-        const double lnfc = flog_half(fma(num, frsqrt(fma(num, num, 1.0)), 1.0), tab);
-        const double d = fmax(1.0 - fexp_c(-(a4 * V[f]), tab), 1e-300);
-        s = fma(kc.om0_grid[f], fexp_c(lnfc * frcp(d), tab), s);      // fc ** (1 / fc_decay)
+        const double sq = fma(num, num, 1.0);
+        // arguments of both exponentials are <= 0: one-sided clamps
+        const double d = fmax(1.0 - fexp_t(fmax(-(a4 * V[f]), -750.0), tab), 1e-100);   // (sd d and Z^2 sd stay finite)
+        // one rsqrt seed for 1/sqrt(sq) and 1/d, as in term_free_fast: Z = 1 / (sqrt(sq) d)
+        const double sd = sq * d;
+        const double Z = frsqrt(sd * d);
+        const double lnfc = flog_half(fma(num, Z * d, 1.0), tab);
+        s = fma(kc.om0_grid[f], fexp_t(fmax(lnfc * ((Z * sd) * Z), -750.0), tab), s);   // fc ** (1 / fc_decay)
     }
     return s;
 }

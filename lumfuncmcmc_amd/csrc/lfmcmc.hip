@@ -59,7 +59,7 @@ struct lf_ctx {
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
-    int64_t opt_taper = 1;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers
+    int64_t opt_taper = 0;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers (second pass over the catalogue)
     int64_t opt_skip_grid = 0;          // 1: leave piece B out (source-sharded ranks other than the first)
     int64_t opt_graph = 0;              // 1: lf_sampler_run replays a captured hipGraph of one ensemble step (opt-in)
     uint64_t generation = 0;            // bumped whenever captured launch arguments go stale (workspace, options)

@@ -34,8 +34,11 @@ for k, cs in summary.items():
     cs["_launches_sampled"] = len(next(iter(pmc[k].values())))
 json.dump(summary, open(os.path.join(here, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
 
-dom = [k for k in summary if "lf_main" in k or "lf_srcsum" in k]
-if dom and "FETCH_SIZE" in summary[dom[0]]:
+# the dominant kernel = the direct lf_main (the bench also times the compressed-catalogue instantiation,
+# whose launches read a few hundred KB): the lf_main with the largest fetch
+dom = sorted([k for k in summary if "lf_main" in k and "FETCH_SIZE" in summary[k]],
+             key=lambda k: -summary[k]["FETCH_SIZE"])
+if dom:
     fetch_kb, write_kb = summary[dom[0]]["FETCH_SIZE"], summary[dom[0]].get("WRITE_SIZE", 0.0)
     tf = os.path.join(here, "hbm_traffic.json")
     d = json.load(open(tf)) if os.path.exists(tf) else {}
