@@ -35,6 +35,12 @@ FLOPS_PER_TERM = {"free": 54.0, "zevol": 27.0, "fixcomp": 0.0}
 # issue cycles one wave spends per term (fp64 VALU 4, v_rcp/v_rsq_f64 16, 32-bit VALU 2.5; measured
 # rates in profiles/r01_ubench.txt), for the issue-utilisation figure
 CYCLES_PER_TERM = {"free": 174.0, "zevol": 81.0, "fixcomp": 0.0}
+# Piece B runs in the same launch.  FREE, per grid node and walker: one Schechter exponential (23 executed flops)
+# and, per field, exp + rsqrt + log + exp: 70 executed flops - from the compiler's assembly of the unrolled walker
+# loop of the grid part (profiles/isa_mix.py: 36 field terms + 8 per-node tails = 2721 flops >= 36 x 70 + 8 x 23).
+# The other variants' grid parts (one or two exponentials per node) are left out of `achieved`.
+FLOPS_PER_NODE = {"free": 23.0, "fixcomp": 0.0, "zevol": 0.0}
+FLOPS_PER_NODE_FIELD = {"free": 70.0, "fixcomp": 0.0, "zevol": 0.0}
 # bytes the per-source loop streams per source and launch: logf_i and U_i = 10^(logf_i + 17) (free: the
 # Schechter part is closed-form per walker, so lum_i is not read); lum, z, z^2 (zevol); nothing (fixcomp).
 # SURVEY.md section 8d also counts 16 B for the free variant.
@@ -225,13 +231,16 @@ def main():
     value = evals / dt
     if rank == 0:
         # dominant kernel = lf_main (per-source sum, piece A, plus the grid integral, piece B, in one
-        # launch); one launch = one half-ensemble call on this GPU.  Flops and bytes below count the
-        # per-source terms only (piece B adds ~7 % more work at N = 1e6 and is left out: conservative)
+        # launch); one launch = one half-ensemble call on this GPU.  Flops = executed fp64 operations of
+        # the per-source terms plus (free variant) those of the grid integral, ~8 % of the total at N = 1e6; bytes
+        # count the catalogue stream only (the grid arrays are cache-resident)
         k = kt["main"]
         launches = max(k["launches"], 1)
         avg_ms = k["ms"] / launches if k["launches"] else dt / args.steps / 2 * 1e3   # no events: the whole call
         terms = float(args.nsrc) * half                                   # (walker, source) terms per launch
-        alg_flops = terms * FLOPS_PER_TERM[args.variant]
+        S, nf = model.size_ln, len(model.Flim)
+        grid_flops = float(half) * S * S * (FLOPS_PER_NODE[args.variant] + nf * FLOPS_PER_NODE_FIELD[args.variant])
+        alg_flops = terms * FLOPS_PER_TERM[args.variant] + grid_flops
         alg_bytes = args.nsrc * BYTES_PER_SOURCE[args.variant] + half * 8 * (ndim + 1)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -247,6 +256,7 @@ def main():
                     "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
                     "terms_per_launch": terms, "flops_per_term_executed": FLOPS_PER_TERM[args.variant],
+                    "flops_per_launch": {"source_terms": terms * FLOPS_PER_TERM[args.variant], "grid_integral": grid_flops},
                     "terms_per_s": terms / (avg_ms * 1e-3),
                     # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the term loop needs
                     "valu_issue_frac_at_2p4GHz": term_waves_per_s * CYCLES_PER_TERM[args.variant] / (1024 * 2.4e9),

@@ -60,6 +60,15 @@ def main():
         for a, b in loops(lines):
             c = mix(lines[a:b + 1])
             fp64 = {k: v for k, v in c.items() if k.startswith("v_") and "f64" in k}
+            if variant == 0 and c.get("v_rsq_f64_e32", 0) >= 30 and not c.get("v_div_scale_f64", 0):
+                # the walker loop of the grid integral (piece B): the switch over nf = 1..8 is unrolled inline, i.e. the
+                # loop body holds 36 field terms (exp, rsqrt, log, exp each) and 8 copies of the per-node tail
+                fma = c["v_fma_f64"] + c["v_fmac_f64_e32"]
+                other = sum(fp64.values()) - fma
+                print("lf_main<variant 0, ST %d>  grid walker loop, all nf = 1..8 cases inline (36 field terms + 8 per-node tails): "
+                      "fp64 fma %d, other fp64 %d -> %d executed flops = 36 x %.1f + 8 x 23 (bench.py counts 70 per node-field + 23 per node)"
+                      % (st, fma, other, 2 * fma + other, (2 * fma + other - 8 * 23) / 36.0))
+                continue
             careful = c.get("v_div_scale_f64", 0) or (c.get("v_cndmask_b32_e64", 0) + c.get("v_cndmask_b32_e32", 0) >= st)
             if b - a < 20 * st or careful:           # skip small loops and the careful (checked) path
                 continue
