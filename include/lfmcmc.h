@@ -135,6 +135,9 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * bin sum, over the whole prior box, is below 1e-16 (csrc/lf_compress.h).  lnprob then costs the grid integral
  * plus a few hundred terms, whatever N is.  Walkers that need the per-source underflow checks are still summed
  * over the real catalogue.  Built at the first call with value 1 (returns LF_ERR_ARG if the bound cannot be met).
+ * With it, FREE contexts whose integration grid is separable (every redshift column has the same luminosity nodes:
+ * min_comp_frac = 0) also take piece B over ~40 x 16 shared flux nodes per field instead of the S^2 lattice points
+ * (same bound; "compress_grid" = 0 keeps the full grid).
  * "graph": 1 lets lf_sampler_run replay one captured hipGraph per ensemble step instead of six launches (same
  * kernels, same random numbers, same chain; the step index then lives in device memory); 0 (default) = plain
  * launches - on ROCm 7.0 the replay gains <= 5 % and shows a sporadic ~30 ms stall, see DESIGN.md.
@@ -181,6 +184,14 @@ int lf_sampler_half_accept(lf_sampler *s, int half, const double *d_newlp, void 
  * node / weight when it is <= cap), or a negative code; *bound = the accepted error bound. */
 int64_t lf_compress_keys(int kind, const double *params, const double *key, const double *wt, int64_t n,
                          double *node, double *weight, int64_t cap, double *bound);
+
+/* Host-only helper behind the compressed grid, exported for tests: S luminosity nodes L with trapezoid weights wL,
+ * S redshift weights ck (trapezoid x dV/dz) and D_k = log10(4 pi DL_k^2); params as for kind 0 of lf_compress_keys.
+ * Outputs per bin: 16 node positions u, first row row0, row count nrows, offset off into omega ([row][node], wL
+ * folded in).  Returns the number of bins (outputs written when the capacities suffice), or a negative code. */
+int64_t lf_compress_grid(const double *params, int S, const double *L, const double *wL, const double *ck,
+                         const double *Dk, double *u, int32_t *row0, int32_t *nrows, int32_t *off, double *omega,
+                         int64_t cap_bins, int64_t cap_omega, double *bound);
 
 /* Last error message of this context (or of lf_create when ctx == NULL).  Never NULL. */
 const char *lf_last_error(const lf_ctx *ctx);

@@ -43,7 +43,7 @@ EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_ba
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
-           "lf_sampler_half_accept", "lf_compress_keys")
+           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid")
 
 _lib = None
 
@@ -137,6 +137,30 @@ def compress_keys(kind, params, key, weight=None):
     if n < 0:
         raise RuntimeError("lf_compress_keys failed (%d): the error bound cannot be met" % n)
     return node[:n].copy(), w[:n].copy(), float(bound[0])
+
+
+def compress_grid(params, L, wL, ck, Dk):
+    """Host-only helper behind the compressed FREE grid (csrc/lf_compress.h: compress_grid).  Returns a dict with
+    u (nb, 16), row0, nrows, off, omega (flat, per bin [row][node]) and bound.  Touches no GPU."""
+    lib = load()
+    params, L, wL, ck, Dk = (_f64(a) for a in (params, L, wL, ck, Dk))
+    S = L.size
+    capb, capo = 4096, 4096 * 16 * 64
+    u = np.empty(capb * 16)
+    row0, nrows, off = (np.empty(capb, dtype=np.int32) for _ in range(3))
+    omega = np.empty(capo)
+    bound = np.zeros(1)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lib.lf_compress_grid.restype = ctypes.c_int64
+    lib.lf_compress_grid.argtypes = [_c_double_p, ctypes.c_int] + [_c_double_p] * 5 + [ip, ip, ip, _c_double_p,
+                                                                                       ctypes.c_int64, ctypes.c_int64, _c_double_p]
+    nb = lib.lf_compress_grid(_ptr(params), S, _ptr(L), _ptr(wL), _ptr(ck), _ptr(Dk), _ptr(u), row0.ctypes.data_as(ip),
+                              nrows.ctypes.data_as(ip), off.ctypes.data_as(ip), _ptr(omega), capb, capo, _ptr(bound))
+    if nb < 0:
+        raise RuntimeError("lf_compress_grid failed (%d)" % nb)
+    nom = int(off[nb - 1] + nrows[nb - 1] * 16)
+    return {"u": u[:nb * 16].reshape(nb, 16).copy(), "row0": row0[:nb].copy(), "nrows": nrows[:nb].copy(),
+            "off": off[:nb].copy(), "omega": omega[:nom].copy(), "bound": float(bound[0])}
 
 
 def _ptr(a):

@@ -28,9 +28,10 @@ namespace lfc {
 constexpr int K = 16;                      // pseudo-sources per bin
 constexpr double COMPRESS_TOL = 1.0e-16;   // bound on the relative error of a bin sum
 constexpr int MAX_DEPTH = 12;
+constexpr double GRID_FLOOR = 1.0e-25;     // kind 2: completeness values below this are bounded absolutely
 
 struct Model {
-    int kind;                              // 0 FREE, 1 ZEVOL
+    int kind;                              // 0 FREE sources, 1 ZEVOL sources, 2 FREE integration grid (see compress_grid)
     double fc_ratio;                       // FREE: |a / (1 - a)|, a = (2 fcmin - 1)^2
     double alpha_lo, alpha_hi;             // FREE: prior box of the completeness slope
     double flim_lo, flim_hi;               // FREE: prior box of Flim (units of 1e-17)
@@ -38,11 +39,11 @@ struct Model {
     double piv[3];                         // ZEVOL: pivots
 };
 
-inline int ncorners(const Model& m) { return m.kind == 0 ? 25 : 8; }
+inline int ncorners(const Model& m) { return m.kind == 1 ? 8 : 25; }
 
 // the function of the source coordinate for prior-box corner `corner`, in long double
 inline long double feval(const Model& m, int corner, long double x) {
-    if (m.kind == 0) {
+    if (m.kind != 1) {
         const int ia = corner / 5, il = corner % 5;
         const long double alo = std::max(m.alpha_lo, 1e-3);
         const long double aC = alo + (std::max<long double>(m.alpha_hi, alo) - alo) * ia / 4.0L;
@@ -56,7 +57,8 @@ inline long double feval(const Model& m, int corner, long double x) {
         const long double lnfc = num >= 0 ? log1pl(-0.5L / (s * (s + num))) : -logl(2.0L * s * (s - num));
         const long double b = -sqrtl((long double)m.fc_ratio / (aC * aC));
         const long double u = powl(10.0L, xs - b);
-        return lnfc / -expm1l(-u);
+        const long double g = lnfc / -expm1l(-u);
+        return m.kind == 2 ? expl(g) : g;               // the grid integrates fc^(1/decay) itself
     }
     // Lagrange form of the quadratic through the pivots (lumfuncmcmc_z.py:26-43 solves the same system), about
     // the middle of the box so that the extrapolated terms cancel as little as possible
@@ -103,6 +105,14 @@ inline double bin_error(const Model& m, double a, double b) {
             const long double fx = feval(m, cr, mid + half * t);
             emax = std::max(emax, fabsl(p - fx));
             fmin = std::min(fmin, fabsl(fx));
+        }
+        if (m.kind == 2) {
+            // F = fc^(1/decay) in (0, 1]: a double evaluation of F = e^g carries |g| ulp of relative noise, so that is
+            // the yardstick; below GRID_FLOOR the bound is absolute (such nodes cannot matter)
+            const long double fm = std::max(fmin, (long double)GRID_FLOOR);
+            if (!std::isfinite((double)emax)) return HUGE_VAL;
+            worst = std::max(worst, emax / (fm * (1.0L + fabsl(logl(fm)))));
+            continue;
         }
         if (!(fmin > 0.0L) || !std::isfinite((double)emax)) return HUGE_VAL;
         worst = std::max(worst, emax / fmin);
@@ -222,6 +232,87 @@ inline bool compress_field(const Model& m, const double* key, const double* wt, 
         }
     }
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The FREE expected-count integral on a SEPARABLE grid (every redshift column has the same luminosity nodes:
+// G[j][k] = L_j, the default min_comp_frac = 0 case):
+//     B_w = sum_j wL_j T_w(L_j) sum_k c_k sum_f om_f F_wf(L_j - D_k),      F_wf(u) = fc^(1/decay) at flux 10^u,
+// c_k = trapezoid weight x dV/dz, D_k = log10(4 pi DL(z_k)^2).  The walker-dependent completeness depends on the
+// lattice point only through u_jk = L_j - D_k, so the S^2 lattice points are binned in u and, ROW BY ROW, replaced
+// by the K Chebyshev nodes of their bin (weights from the row's moments in the bin, exactly as for the sources):
+//     sum_k c_k F(u_jk) ~ sum_b sum_n Omega[b][n][j] F(u_bn),   B_w ~ sum_b sum_n F-sum(u_bn) sum_j T_w(L_j) Omega'[b][n][j]
+// (Omega' = wL_j Omega).  All rows share the nodes of a bin: 16 x (number of bins) completeness evaluations per
+// field instead of S^2, plus a short dot product with T_w over the ~20 rows that cross the bin.
+struct GridOut {
+    std::vector<double> u;              // [nb * K] node positions (log10 flux)
+    std::vector<int> row0, nrows, off;  // per bin: first row, row count, offset into omega
+    std::vector<double> omega;          // per bin [row][node]
+    double bound = 0.0;
+    int nb = 0;
+};
+
+inline bool compress_grid(const Model& m, int S, const double* L, const double* wL, const double* ck, const double* Dk, GridOut& out) {
+    if (S < 2) return false;
+    double dmin = Dk[0], dmax = Dk[0];
+    for (int k = 0; k < S; ++k) {
+        if (!std::isfinite(Dk[k]) || !std::isfinite(ck[k])) return false;
+        dmin = std::min(dmin, Dk[k]);
+        dmax = std::max(dmax, Dk[k]);
+    }
+    double lmin = L[0], lmax = L[0];
+    for (int j = 0; j < S; ++j) {
+        if (!std::isfinite(L[j]) || !std::isfinite(wL[j])) return false;
+        lmin = std::min(lmin, L[j]);
+        lmax = std::max(lmax, L[j]);
+    }
+    const double lo = lmin - dmax, hi = lmax - dmin;
+    if (!(hi > lo)) return false;
+    std::vector<double> edges;
+    const double bound = make_bins(m, lo, hi, 0.2, edges);
+    if (!(bound < HUGE_VAL)) return false;
+    out.bound = bound;
+    const int nb = (int)edges.size() - 1;
+    const long double PI = 3.141592653589793238462643383279502884L;
+    for (int b = 0; b < nb; ++b) {
+        const long double mid = 0.5L * ((long double)edges[b] + edges[b + 1]), half = 0.5L * ((long double)edges[b + 1] - edges[b]);
+        const bool last = b == nb - 1;
+        int j0 = S, j1 = -1;
+        std::vector<long double> mom((size_t)S * K, 0.0L);
+        for (int j = 0; j < S; ++j)
+            for (int k = 0; k < S; ++k) {
+                const double u = L[j] - Dk[k];                       // the very rounding the device tables use
+                if (!(u >= edges[b] && (u < edges[b + 1] || (last && u <= edges[b + 1])))) continue;
+                j0 = std::min(j0, j);
+                j1 = std::max(j1, j);
+                const long double t = std::min(1.0L, std::max(-1.0L, ((long double)u - mid) / half));
+                long double* M = &mom[(size_t)j * K];
+                long double t0 = 1.0L, t1 = t;
+                M[0] += ck[k];
+                M[1] += ck[k] * t;
+                for (int q = 2; q < K; ++q) {
+                    const long double t2 = 2.0L * t * t1 - t0;
+                    M[q] += ck[k] * t2;
+                    t0 = t1;
+                    t1 = t2;
+                }
+            }
+        if (j1 < j0) continue;                                        // no lattice point in this bin
+        out.row0.push_back(j0);
+        out.nrows.push_back(j1 - j0 + 1);
+        out.off.push_back((int)out.omega.size());
+        for (int n = 0; n < K; ++n) out.u.push_back((double)(mid + half * cosl(PI * (n + 0.5L) / K)));
+        for (int j = j0; j <= j1; ++j)
+            for (int n = 0; n < K; ++n) {
+                const long double th = PI * (n + 0.5L) / K;
+                const long double* M = &mom[(size_t)j * K];
+                long double w = M[0];
+                for (int q = 1; q < K; ++q) w += 2.0L * cosl(q * th) * M[q];
+                out.omega.push_back((double)(wL[j] * w / K));
+            }
+        ++out.nb;
+    }
+    return out.nb > 0;
 }
 
 }  // namespace lfc

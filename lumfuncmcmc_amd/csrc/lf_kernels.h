@@ -213,9 +213,12 @@ __device__ __forceinline__ int group8_or(int v) {
     return v;
 }
 
+// slow: {count, list...} of the walkers flagged STAT_SLOW, for the rescue workgroups of the compressed-catalogue
+// launch (order = arrival order of the atomics; every walker's sums go to its own slots, so the order is immaterial);
+// lf_finalize resets the count.
 __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const double* __restrict__ theta, int B,
                                                  double* __restrict__ wrec, int* __restrict__ wstat,
-                                                 int* __restrict__ wmode, double* __restrict__ wbase) {
+                                                 int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list) {
     __shared__ double sth[8][16];
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int wq = gt >> 3, f = gt & 7, grp = threadIdx.x >> 3;
@@ -348,6 +351,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     if (live && f == 0) {
         wbase[w] = base;
         wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0);
+        if (slow && slow_list) slow_list[1 + atomicAdd(slow_list, 1)] = w;
     }
 }
 
@@ -414,14 +418,15 @@ __device__ __forceinline__ double lnT_zevol(const WZ& w, double lum, double z, d
 // ----------------------------------------------------------------------------------------------
 // block reduction: red[nw][256] (LDS) -> out[(w0 + w) * stride + chunk]
 // ----------------------------------------------------------------------------------------------
+// widx: optional list of walker indices (the tile is widx[0 .. nw-1] instead of w0 .. w0+nw-1)
 __device__ __forceinline__ void reduce_store(const double* __restrict__ red, int nw, double* __restrict__ out,
-                                             size_t stride, int w0, int chunk) {
+                                             size_t stride, int w0, int chunk, const int* __restrict__ widx = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int w = wave; w < nw; w += BLOCK / 64) {
         const double* row = red + w * BLOCK;
         double s = (row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]);
         s = wave_sum(s);
-        if (lane == 0) out[(size_t)(w0 + w) * stride + chunk] = s;
+        if (lane == 0) out[(size_t)(widx ? widx[w] : w0 + w) * stride + chunk] = s;
     }
 }
 
@@ -443,11 +448,15 @@ struct SrcArrays {
 // CMP = the items are the pseudo-sources of the compressed catalogue (lfmcmc.hip: build_compressed): each
 // carries a weight, and walkers that need the per-source underflow checks are left out (they are summed over
 // the real catalogue by the rescue workgroups of the same launch).
-template <int VARIANT, int ST, int TW, bool CMP>
+// IDX = the walker tile is a list, widx[0 .. nw-1] (the rescue workgroups' tiles of flagged walkers), instead of
+// the contiguous w0 .. w0+nw-1.
+template <int VARIANT, int ST, int TW, bool CMP, bool IDX = false>
 __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& sa, const double* __restrict__ wrec,
                                             const int* __restrict__ wmode, int c, int w0, int nw,
                                             double* __restrict__ partial, int pstride,
-                                            const MathTables& tab, double* __restrict__ red) {
+                                            const MathTables& tab, double* __restrict__ red,
+                                            const int* __restrict__ widx = nullptr) {
+    auto wi = [&](int w) -> size_t { return (size_t)(IDX ? widx[w] : w0 + w); };
     // one item: catalogue chunk c x walkers w0 .. w0+nw-1 (nw <= TW, which sizes the LDS buffer)
     const int tid = threadIdx.x;
     const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
@@ -456,9 +465,9 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
         // piece A is closed-form (wbase): unless one of the tile's walkers needs the per-term underflow
         // checks there is nothing to do here - do not even read the catalogue
         int any_slow = 0;
-        for (int w = 0; w < nw; ++w) any_slow |= (wmode[(size_t)(w0 + w) * MAXF + fld] == MODE_SLOW);
+        for (int w = 0; w < nw; ++w) any_slow |= (wmode[wi(w) * MAXF + fld] == MODE_SLOW);
         if (!__builtin_amdgcn_readfirstlane(any_slow)) {
-            if (tid < nw) partial[(size_t)(w0 + tid) * pstride + c] = 0.0;
+            if (tid < nw) partial[wi(tid) * pstride + c] = 0.0;
             return;
         }
     }
@@ -486,9 +495,9 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     // depends on which other walkers share its tile (lnprob is a function of its theta row alone).
     double nxA = 0.0, nxC = 0.0, nxV = 0.0;
     WZ nz{};
-    int nxm = wmode[(size_t)w0 * MAXF + fld];
+    int nxm = wmode[wi(0) * MAXF + fld];
     {
-        const double* __restrict__ r0 = wrec + (size_t)w0 * REC;
+        const double* __restrict__ r0 = wrec + wi(0) * REC;
         if (VARIANT == LF_FREE) {
             nxA = r0[R_ALPHAC];
             nxC = r0[R_CA + fld];
@@ -499,8 +508,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
 #pragma unroll 1
     for (int w = 0; w < nw; ++w) {
         const int mode = __builtin_amdgcn_readfirstlane(nxm);
-        const double* __restrict__ rn = wrec + (size_t)(w0 + min(w + 1, nw - 1)) * REC;
-        nxm = wmode[(size_t)(w0 + min(w + 1, nw - 1)) * MAXF + fld];
+        const double* __restrict__ rn = wrec + wi(min(w + 1, nw - 1)) * REC;
+        nxm = wmode[wi(min(w + 1, nw - 1)) * MAXF + fld];
         double acc = 0.0;
         if (mode != MODE_SLOW) {
             if (VARIANT == LF_FREE) {
@@ -541,7 +550,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             // careful path (rare): device-library math, per-term underflow checks, -inf poisoning.  Items
             // are re-read from memory inside a rolled loop so that this path adds no register pressure
             // to the fast one.
-            const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+            const double* __restrict__ r = wrec + wi(w) * REC;
             if (VARIANT == LF_FREE) {
                 nxA = rn[R_ALPHAC];
                 nxC = rn[R_CA + fld];
@@ -579,7 +588,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
         red[w * BLOCK + tid] = acc;
     }
     __syncthreads();
-    reduce_store(red, nw, partial, (size_t)pstride, w0, c);
+    reduce_store(red, nw, partial, (size_t)pstride, w0, c, IDX ? widx : nullptr);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -624,6 +633,20 @@ __device__ __forceinline__ double field_sum(const KConst& kc, const double* __re
     return s;
 }
 
+__device__ __forceinline__ double field_sum_nf(const KConst& kc, const double* __restrict__ r, double alphaC, double a3,
+                                               double a4, const MathTables* __restrict__ tab) {
+    switch (kc.nf) {
+        case 1: return field_sum<1>(kc, r, alphaC, a3, a4, tab);
+        case 2: return field_sum<2>(kc, r, alphaC, a3, a4, tab);
+        case 3: return field_sum<3>(kc, r, alphaC, a3, a4, tab);
+        case 4: return field_sum<4>(kc, r, alphaC, a3, a4, tab);
+        case 5: return field_sum<5>(kc, r, alphaC, a3, a4, tab);
+        case 6: return field_sum<6>(kc, r, alphaC, a3, a4, tab);
+        case 7: return field_sum<7>(kc, r, alphaC, a3, a4, tab);
+        default: return field_sum<8>(kc, r, alphaC, a3, a4, tab);
+    }
+}
+
 template <int VARIANT, int TW>
 __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays& na, const double* __restrict__ wrec,
                                              int B, int ntiles, int tw, int id, double* __restrict__ partial,
@@ -644,17 +667,7 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
         if (VARIANT == LF_FREE) {
             const double T = fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
             const double alphaC = r[R_ALPHAC];
-            double s;
-            switch (kc.nf) {
-                case 1: s = field_sum<1>(kc, r, alphaC, a3, a4, &tab); break;
-                case 2: s = field_sum<2>(kc, r, alphaC, a3, a4, &tab); break;
-                case 3: s = field_sum<3>(kc, r, alphaC, a3, a4, &tab); break;
-                case 4: s = field_sum<4>(kc, r, alphaC, a3, a4, &tab); break;
-                case 5: s = field_sum<5>(kc, r, alphaC, a3, a4, &tab); break;
-                case 6: s = field_sum<6>(kc, r, alphaC, a3, a4, &tab); break;
-                case 7: s = field_sum<7>(kc, r, alphaC, a3, a4, &tab); break;
-                default: s = field_sum<8>(kc, r, alphaC, a3, a4, &tab);
-            }
+            const double s = field_sum_nf(kc, r, alphaC, a3, a4, &tab);
             val = W * T * s;
         } else if (VARIANT == LF_FIXCOMP) {
             val = W * fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
@@ -664,6 +677,67 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
             val = W * fexp_c(lnT_zevol<true>(wz, G, a3, a4, v, &tab), &tab);
         }
         red[w * BLOCK + tid] = val;
+    }
+    __syncthreads();
+    reduce_store(red, nw, partial, (size_t)pstride, w0, c);
+}
+
+// ----------------------------------------------------------------------------------------------
+// piece B on the COMPRESSED grid (FREE, separable grid; csrc/lf_compress.h: compress_grid).  The S^2 lattice
+// points are replaced by 16 nodes per flux bin, shared by all rows:
+//     B_w ~ sum_b sum_n [ sum_f om_f F_wf(u_bn) ] * [ sum_r T_w(L_{row0_b + r}) omega_b[r][n] ]
+// A workgroup owns 16 bins (thread = (bin, node)) x a walker tile.  Per walker it first puts the S Schechter
+// values T_w(L_j) in LDS (one exponential per thread), then every thread takes its node's field sum (the same
+// field_sum as the full grid) times its short dot product with T_w.
+// ----------------------------------------------------------------------------------------------
+constexpr int GRIDC_MAX_S = 512;
+struct GridC {
+    const double* U;       // [nb * 16] node log-flux
+    const double* A4;      // [nb * 16] 10^(U + 17)
+    const int* row0;       // [nb]
+    const int* nrows;      // [nb]
+    const int* off;        // [nb] offset of omega_b
+    const double* omega;   // per bin [row][node], trapezoid weights folded in
+    const double* L;       // [S] luminosity nodes
+    const double* PGL;     // [S] 10^(L - 42)
+    int nb, S;
+};
+
+template <int TW>
+__device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, const double* __restrict__ wrec, int B,
+                                           int ntiles, int tw, int id, double* __restrict__ partial, int pstride,
+                                           const MathTables& tab, double* __restrict__ red, double* __restrict__ Tw) {
+    const int tid = threadIdx.x;
+    const int c = id / ntiles, tile = id - c * ntiles;
+    const int w0 = tile * tw;
+    const int nw = min(tw, B - w0);
+    const int b = c * 16 + (tid >> 4), n = tid & 15;
+    const bool valid = b < gc.nb;
+    const int bb = valid ? b : 0;
+    const double u = gc.U[bb * 16 + n], a4 = gc.A4[bb * 16 + n];
+    const int j0 = gc.row0[bb], nr = valid ? gc.nrows[bb] : 0;
+    const double* __restrict__ om = gc.omega + gc.off[bb] + n;
+    double Lj[GRIDC_MAX_S / BLOCK], PGj[GRIDC_MAX_S / BLOCK];
+#pragma unroll
+    for (int q = 0; q < GRIDC_MAX_S / BLOCK; ++q) {
+        const int j = min(tid + q * BLOCK, gc.S - 1);
+        Lj[q] = gc.L[j];
+        PGj[q] = gc.PGL[j];
+    }
+#pragma unroll 1
+    for (int w = 0; w < nw; ++w) {
+        const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+        __syncthreads();                                   // the previous walker's T_w has been read
+#pragma unroll
+        for (int q = 0; q < GRIDC_MAX_S / BLOCK; ++q) {
+            const int j = tid + q * BLOCK;
+            if (j < gc.S) Tw[j] = fexp_c(fma(r[R_C1], Lj[q] - r[R_LSTAR], r[R_C0]) - PGj[q] * r[R_Q], &tab);
+        }
+        __syncthreads();
+        double R = 0.0;
+        for (int k = 0; k < nr; ++k) R = fma(Tw[j0 + k], om[k * 16], R);
+        const double Fs = field_sum_nf(kc, r, r[R_ALPHAC], u, a4, &tab);
+        red[w * BLOCK + tid] = R * Fs;
     }
     __syncthreads();
     reduce_store(red, nw, partial, (size_t)pstride, w0, c);
@@ -699,6 +773,8 @@ struct Tiling {
 struct Rescue {
     SrcArrays sd;
     const int* wstat;
+    const int* slow_list;       // walkers flagged STAT_SLOW by lf_prepare, in arrival order
+    const int* slow_count;      // how many
     double* partR;
     int nchD, nresc;
     unsigned long long* bump;   // sampler step counter to advance (graph replay, half 0 only), or NULL
@@ -709,32 +785,36 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
                                                  const double* __restrict__ wrec, const int* __restrict__ wmode,
                                                  int B, Tiling tl, int nchA, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
-                                                 double* __restrict__ partB, int strideB, Rescue rs) {
+                                                 double* __restrict__ partB, int strideB, Rescue rs, GridC gc) {
     __shared__ MathTables tab;
     __shared__ double red[(TW > TWB ? TW : TWB) * BLOCK];
+    __shared__ double Tw[CMP ? GRIDC_MAX_S : 1];
+    if (CMP) {
+        // rescue workgroups have nothing to do unless lf_prepare listed a walker: leave before the table prologue
+        const int first_resc = nblkB + nchA * (tl.ntiles + tl.ntiles_s);
+        if ((int)blockIdx.x >= first_resc && *rs.slow_count == 0) return;
+    }
     load_tables(&tab);
     if (rs.bump && blockIdx.x == 0 && threadIdx.x == 0) *rs.bump += 1ull;   // no reader of the counter in this launch
     __syncthreads();
     int id = blockIdx.x;
     if (id < nblkB) {
-        gridsum_body<VARIANT, TWB>(kc, na, wrec, B, ntilesB, twb, id, partB, strideB, tab, red);
+        if (CMP && VARIANT == LF_FREE && gc.nb > 0) gridc_body<TWB>(kc, gc, wrec, B, ntilesB, twb, id, partB, strideB, tab, red, Tw);
+        else gridsum_body<VARIANT, TWB>(kc, na, wrec, B, ntilesB, twb, id, partB, strideB, tab, red);
         return;
     }
     id -= nblkB;
     const int nbig = nchA * tl.ntiles;
     if (CMP && id >= nbig + nchA * tl.ntiles_s) {
+        // items = (chunk of the real catalogue) x (tile of up to TW listed walkers), dealt round-robin
         const int r = id - (nbig + nchA * tl.ntiles_s);
-        for (int wb = 0; wb < B; wb += 64) {
-            const int wl = wb + (threadIdx.x & 63);
-            unsigned long long todo = __ballot(wl < B && (rs.wstat[wl < B ? wl : 0] & STAT_SLOW));   // the same in all four waves
-            while (todo) {
-                const int w = wb + __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                for (int c = r; c < rs.nchD; c += rs.nresc) {
-                    srcsum_body<VARIANT, ST, TW, false>(kc, rs.sd, wrec, wmode, c, w, 1, rs.partR, rs.nchD, tab, red);
-                    __syncthreads();
-                }
-            }
+        const int nslow = *rs.slow_count;
+        const int nt = (nslow + TW - 1) / TW;
+        for (long long it = r; it < (long long)rs.nchD * nt; it += rs.nresc) {
+            const int c = (int)(it / nt), t = (int)(it - (long long)c * nt);
+            srcsum_body<VARIANT, ST, TW, false, true>(kc, rs.sd, wrec, wmode, c, 0, min(TW, nslow - t * TW), rs.partR, rs.nchD, tab, red,
+                                                      rs.slow_list + t * TW);
+            __syncthreads();
         }
         return;
     }
@@ -815,9 +895,10 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
                                                   const int* __restrict__ wstat,
                                                   const double* __restrict__ wbase, int B, AcceptArgs ap,
                                                   double* __restrict__ out, double* __restrict__ outA,
-                                                  double* __restrict__ outB) {
+                                                  double* __restrict__ outB, int* __restrict__ slow_list) {
     const int w = blockIdx.x;
     if (w >= B) return;
+    if (slow_list && w == 0 && threadIdx.x == 0) slow_list[0] = 0;     // lf_main has consumed the list
     const int lane = threadIdx.x;
     double a = 0.0, b = 0.0;
     // compressed catalogue: a walker flagged SLOW was summed over the real catalogue by the rescue workgroups

@@ -64,8 +64,21 @@ struct lf_ctx {
     int64_t opt_graph = 0;              // 1: lf_sampler_run replays a captured hipGraph of one ensemble step (opt-in)
     uint64_t generation = 0;            // bumped whenever captured launch arguments go stale (workspace, options)
     int64_t opt_compress = 0;           // 1: piece A from the compressed catalogue (FREE, ZEVOL)
+    int64_t opt_compress_grid = 1;      // with compress: also the FREE integration grid, when it is separable
     CompressedCat cmp;
+    // FREE: the factors of a separable integration grid (every redshift column has the same luminosity nodes),
+    // kept on the host for the compressed grid; empty when the grid is not separable
+    std::vector<double> h_L, h_wL, h_ck, h_Dk;
+    struct {
+        bool built = false;
+        int nb = 0;
+        double bound = 0.0;
+        double *d_U = nullptr, *d_A4 = nullptr, *d_omega = nullptr, *d_L = nullptr, *d_PGL = nullptr;
+        int *d_row0 = nullptr, *d_nrows = nullptr, *d_off = nullptr;
+    } gridc;
     double* d_partR = nullptr;          // rescue partials [B][chunks of the real catalogue]
+    int* d_slow = nullptr;              // {count, walker indices...} of the walkers lf_prepare flagged SLOW (compressed mode)
+    int cap_slow = 0;
     size_t cap_partR = 0;
     // workspace
     int cap_B = 0;                      // padded walker capacity
@@ -165,6 +178,10 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         LF_HIP(c, hipMalloc((void**)&c->d_wstat, (size_t)nb * sizeof(int)));
         LF_HIP(c, hipMalloc((void**)&c->d_wmode, (size_t)nb * lf::MAXF * sizeof(int)));
         LF_HIP(c, hipMalloc((void**)&c->d_wbase, (size_t)nb * sizeof(double)));
+        if (c->d_slow) hipFree(c->d_slow);
+        c->d_slow = nullptr;
+        LF_HIP(c, hipMalloc((void**)&c->d_slow, ((size_t)nb + 1) * sizeof(int)));
+        LF_HIP(c, hipMemset(c->d_slow, 0, ((size_t)nb + 1) * sizeof(int)));
         LF_HIP(c, hipHostMalloc((void**)&c->h_theta, (size_t)nb * 16 * sizeof(double), hipHostMallocDefault));
         LF_HIP(c, hipHostMalloc((void**)&c->h_out, (size_t)nb * 3 * sizeof(double), hipHostMallocDefault));
         c->cap_B = nb;
@@ -222,22 +239,23 @@ struct Prof {
 template <int VARIANT, int GI, bool CMP = false>
 void launch_geo(lf_ctx* c, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int nblkB, hipStream_t s,
                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB,
-                const lf::Rescue& rs = lf::Rescue{}) {
+                const lf::Rescue& rs = lf::Rescue{}, const lf::GridC& gc = lf::GridC{}) {
     using namespace lf;
     hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, CMP>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                       na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB, rs);
+                       na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB, rs, gc);
 }
 
 // compressed-catalogue launches: the pseudo-sources are few, so only the small-tile geometries are instantiated
 constexpr int CMP_GEOS[] = {8, 1, 4, 2};     // [0] is the default: few sources per lane, 16 walkers per grid workgroup
 template <int VARIANT>
 void launch_main_cmp(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int nblkB, hipStream_t s,
-                     const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB, const lf::Rescue& rs) {
+                     const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB, const lf::Rescue& rs,
+                     const lf::GridC& gc) {
     switch (gi) {
-        case 1: launch_geo<VARIANT, 1, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
-        case 4: launch_geo<VARIANT, 4, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
-        case 2: launch_geo<VARIANT, 2, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
-        default: launch_geo<VARIANT, 8, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
+        case 1: launch_geo<VARIANT, 1, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs, gc); break;
+        case 4: launch_geo<VARIANT, 4, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs, gc); break;
+        case 2: launch_geo<VARIANT, 2, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs, gc); break;
+        default: launch_geo<VARIANT, 8, true>(c, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs, gc);
     }
 }
 
@@ -281,8 +299,9 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd)) != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchD = cmp ? ctd->n : 0;
-    const int nresc = cmp ? std::min(nchD, 256) : 0;
-    const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + BLOCK - 1) / BLOCK;
+    const int nresc = cmp ? std::min(nchD, 1024) : 0;      // they leave at once unless a walker was flagged
+    const bool cgrid = cmp && c->gridc.built && c->opt_compress_grid && !c->opt_skip_grid;
+    const int nchB = c->opt_skip_grid ? 0 : (cgrid ? (c->gridc.nb + 15) / 16 : (c->nnodes + BLOCK - 1) / BLOCK);
     rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * nchD);
     if (rc != LF_OK) return rc;
     if (bump && nchB * (int64_t)B + nchA <= 0) {
@@ -297,12 +316,17 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 0);
         hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
-                           c->d_wstat, c->d_wmode, c->d_wbase);
+                           c->d_wstat, c->d_wmode, c->d_wbase, cmp ? c->d_slow : nullptr);
     }
     const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field};
     SrcArrays sa = sd;
     Rescue rs{};
     rs.bump = bump;
+    GridC gc{};
+    if (cgrid) {
+        const auto& g = c->gridc;
+        gc = GridC{g.d_U, g.d_A4, g.d_row0, g.d_nrows, g.d_off, g.d_omega, g.d_L, g.d_PGL, g.nb, c->kc.S};
+    }
     if (cmp) {
         sa = SrcArrays{c->cmp.d_lum, c->cmp.d_a1, c->cmp.d_lum, c->cmp.d_U, c->cmp.d_W, ct->d_start, ct->d_len, ct->d_field};
         rs.sd = sd;
@@ -310,6 +334,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         rs.sd.chunk_len = ctd->d_len;
         rs.sd.chunk_field = ctd->d_field;
         rs.wstat = c->d_wstat;
+        rs.slow_count = c->d_slow;
+        rs.slow_list = c->d_slow + 1;
         rs.partR = c->d_partR;
         rs.nchD = nchD;
         rs.nresc = nresc;
@@ -321,8 +347,10 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         if (cmp && nchB > 0) {
             // the grid integral is all the work there is: walkers per grid workgroup such that the launch
             // still has ~2000 workgroups (8 per CU), as many as the instantiation allows otherwise
+            // (the compressed grid has only a few bin groups, each workgroup little work per walker: fewer, fatter ones)
+            const int64_t want = cgrid ? 768 : 2048;
             int t = 1;
-            while (t < geo.twb && (int64_t)nchB * ((B + 2 * t - 1) / (2 * t)) >= 2048) t *= 2;
+            while (t < geo.twb && (int64_t)nchB * ((B + 2 * t - 1) / (2 * t)) >= want) t *= 2;
             twb = t;
         }
         if (c->opt_walker_tile > 0) {
@@ -343,8 +371,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         dim3 grid((unsigned)(nblkB + nchA * (tl.ntiles + tl.ntiles_s) + nresc));
         if (grid.x > 0) {
             if (cmp) {
-                if (c->kc.variant == LF_FREE) launch_main_cmp<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
-                else launch_main_cmp<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs);
+                if (c->kc.variant == LF_FREE) launch_main_cmp<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs, gc);
+                else launch_main_cmp<LF_ZEVOL>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs, gc);
             } else switch (c->kc.variant) {
                 case LF_FREE: launch_main<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
                 case LF_FIXCOMP: launch_main<LF_FIXCOMP>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs); break;
@@ -355,7 +383,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           cmp ? c->d_partR : nullptr, nchD, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB);
+                           cmp ? c->d_partR : nullptr, nchD, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB,
+                           cmp ? c->d_slow : nullptr);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;
@@ -425,6 +454,30 @@ int build_compressed(lf_ctx* c) {
     if ((rc = upload(c, &cc.d_W, out.weight.data(), (size_t)cc.n)) != LF_OK) return rc;
     cc.built = true;
     c->cmp = cc;
+    // the integration grid, when it is separable (a failure here only leaves the full grid in use)
+    if (c->kc.variant == LF_FREE && !c->h_L.empty() && !c->gridc.built) {
+        lfc::Model mg = m;
+        mg.kind = 2;
+        lfc::GridOut go;
+        const int S = c->kc.S;
+        if (lfc::compress_grid(mg, S, c->h_L.data(), c->h_wL.data(), c->h_ck.data(), c->h_Dk.data(), go)) {
+            std::vector<double> A4(go.u.size()), PGL((size_t)S);
+            for (size_t i = 0; i < go.u.size(); ++i) A4[i] = std::pow(10.0, go.u[i] - LF_FREF);
+            for (int j = 0; j < S; ++j) PGL[(size_t)j] = std::pow(10.0, c->h_L[(size_t)j] - LF_LREF);
+            auto& g = c->gridc;
+            if ((rc = upload(c, &g.d_U, go.u.data(), go.u.size())) != LF_OK) return rc;
+            if ((rc = upload(c, &g.d_A4, A4.data(), A4.size())) != LF_OK) return rc;
+            if ((rc = upload(c, &g.d_omega, go.omega.data(), go.omega.size())) != LF_OK) return rc;
+            if ((rc = upload(c, &g.d_L, c->h_L.data(), (size_t)S)) != LF_OK) return rc;
+            if ((rc = upload(c, &g.d_PGL, PGL.data(), (size_t)S)) != LF_OK) return rc;
+            if ((rc = upload(c, &g.d_row0, go.row0.data(), go.row0.size())) != LF_OK) return rc;
+            if ((rc = upload(c, &g.d_nrows, go.nrows.data(), go.nrows.size())) != LF_OK) return rc;
+            if ((rc = upload(c, &g.d_off, go.off.data(), go.off.size())) != LF_OK) return rc;
+            g.nb = go.nb;
+            g.bound = go.bound;
+            g.built = true;
+        }
+    }
     return LF_OK;
 }
 
@@ -443,6 +496,15 @@ void free_ctx(lf_ctx* c) {
     }
     free_cmp(c->cmp);
     if (c->d_partR) hipFree(c->d_partR);
+    {
+        auto& g = c->gridc;
+        double* gb[] = {g.d_U, g.d_A4, g.d_omega, g.d_L, g.d_PGL};
+        for (double* b : gb)
+            if (b) hipFree(b);
+        int* gi_[] = {g.d_row0, g.d_nrows, g.d_off};
+        for (int* b : gi_)
+            if (b) hipFree(b);
+    }
     double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4,
                       c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
     for (double* b : bufs)
@@ -450,6 +512,7 @@ void free_ctx(lf_ctx* c) {
     if (c->d_wstat) hipFree(c->d_wstat);
     if (c->d_wmode) hipFree(c->d_wmode);
     if (c->d_wbase) hipFree(c->d_wbase);
+    if (c->d_slow) hipFree(c->d_slow);
     if (c->h_theta) hipHostFree(c->h_theta);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -597,6 +660,30 @@ int build(lf_ctx* c, const lf_desc* d) {
                     a3[g] = d->zarr[k];
                     a4[g] = d->zarr[k] * d->zarr[k];
                 }
+            }
+        }
+    }
+    if (d->variant == LF_FREE && S <= GRIDC_MAX_S) {
+        bool sep = true;
+        for (int j = 0; j < S && sep; ++j)
+            for (int k = 1; k < S; ++k)
+                if (d->logL[(size_t)j * S + k] != d->logL[(size_t)j * S]) {
+                    sep = false;
+                    break;
+                }
+        if (sep) {
+            c->h_L.resize(S); c->h_wL.resize(S); c->h_ck.resize(S); c->h_Dk.resize(S);
+            for (int j = 0; j < S; ++j) {
+                const double x = d->logL[(size_t)j * S];
+                const double dl = j > 0 ? x - d->logL[(size_t)(j - 1) * S] : 0.0;
+                const double dr = j < S - 1 ? d->logL[(size_t)(j + 1) * S] - x : 0.0;
+                c->h_L[j] = x;
+                c->h_wL[j] = 0.5 * (dl + dr);
+            }
+            for (int k = 0; k < S; ++k) {
+                const double dlcm = LF_MPC_CM * d->dl_zarr[k];
+                c->h_Dk[k] = std::log10(4.0 * M_PI * dlcm * dlcm);
+                c->h_ck[k] = wz[k] * d->volume_part[k];
             }
         }
     }
@@ -792,6 +879,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
         c->opt_compress = value != 0;
         return LF_OK;
     }
+    if (std::strcmp(key, "compress_grid") == 0) {
+        c->opt_compress_grid = value != 0;
+        return LF_OK;
+    }
     if (std::strcmp(key, "skip_grid") == 0) {
         c->opt_skip_grid = value != 0;
         return LF_OK;
@@ -832,6 +923,29 @@ int64_t lf_compress_keys(int kind, const double* params, const double* key, cons
     std::copy(out.node.begin(), out.node.end(), node);
     std::copy(out.weight.begin(), out.weight.end(), weight);
     return cnt;
+}
+
+int64_t lf_compress_grid(const double* params, int S, const double* L, const double* wL, const double* ck, const double* Dk,
+                         double* u, int32_t* row0, int32_t* nrows, int32_t* off, double* omega, int64_t cap_bins,
+                         int64_t cap_omega, double* bound) {
+    if (!params || !L || !wL || !ck || !Dk || S < 2) return LF_ERR_ARG;
+    lfc::Model m{};
+    m.kind = 2;
+    m.fc_ratio = params[0];
+    m.alpha_lo = params[1];
+    m.alpha_hi = params[2];
+    m.flim_lo = params[3];
+    m.flim_hi = params[4];
+    lfc::GridOut g;
+    if (!lfc::compress_grid(m, S, L, wL, ck, Dk, g)) return LF_ERR_ARG;
+    if (bound) *bound = g.bound;
+    if (g.nb > cap_bins || (int64_t)g.omega.size() > cap_omega || !u || !row0 || !nrows || !off || !omega) return g.nb;
+    std::copy(g.u.begin(), g.u.end(), u);
+    std::copy(g.row0.begin(), g.row0.end(), row0);
+    std::copy(g.nrows.begin(), g.nrows.end(), nrows);
+    std::copy(g.off.begin(), g.off.end(), off);
+    std::copy(g.omega.begin(), g.omega.end(), omega);
+    return g.nb;
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -81,3 +81,35 @@ def test_small_and_degenerate_inputs_are_kept_as_they_are():
     assert node.size == 0
     with pytest.raises(RuntimeError):
         compress_keys(0, [FR, 1.0, 6.0, 1.0, 6.0], np.array([np.nan] * 40))
+
+
+def test_compressed_grid_reproduces_the_double_sum():
+    """sum_j wL_j T_j sum_k c_k F(L_j - D_k - lF) over the S^2 lattice against the shared-node form
+    sum_b sum_n F(u_bn - lF) sum_r T_{row0_b + r} omega_b[r][n] (csrc/lf_compress.h: compress_grid), long double."""
+    from lumfuncmcmc_amd.capi import compress_grid
+    S = 101
+    L = np.linspace(41.0, 43.5, S)
+    wL = np.full(S, L[1] - L[0]); wL[[0, -1]] *= 0.5
+    z = np.linspace(1.16, 1.90, S)
+    Dk = 57.9 + 0.5 * (z - 1.16) / 0.74 - 0.1 * (z - 1.16) * (z - 1.9)       # log10(4 pi DL^2)-like, monotonic
+    ck = (1 + 0.1 * z) * (z[1] - z[0]); ck[[0, -1]] *= 0.5
+    g = compress_grid([FR, 1.0, 6.0, 1.0, 6.0], L, wL, ck, Dk)
+    nb = g["u"].shape[0]
+    assert g["bound"] <= 1e-16 and nb * 16 < S * S // 8
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for t in range(12):
+        aC = (1.0, 6.0, 6.0)[t] if t < 3 else rng.uniform(1, 6)
+        Fl = (1.0, 6.0, 1.0)[t] if t < 3 else rng.uniform(1, 6)
+        lF = np.log10(Fl) - 17
+        T = np.exp(LD(-0.8) * (L.astype(LD) - 42) - LD(10) ** (L.astype(LD) - rng.uniform(41.8, 43.0)))   # Schechter-like row factor
+        F = lambda u: np.exp(g_free(np.asarray(u, dtype=LD) - lF, aC))
+        full = sum(wL[j] * T[j] * (ck.astype(LD) * F(L[j] - Dk)).sum() for j in range(S))
+        comp = LD(0)
+        for b in range(nb):
+            om = g["omega"][g["off"][b]:g["off"][b] + g["nrows"][b] * 16].reshape(g["nrows"][b], 16).astype(LD)
+            R = (T[g["row0"][b]:g["row0"][b] + g["nrows"][b], None] * om).sum(axis=0)
+            comp += (R * F(g["u"][b])).sum()
+        worst = max(worst, float(abs(comp - full) / full))
+    print("compressed grid: %d bins -> %d nodes (of %d lattice points), worst rel %.2e" % (nb, nb * 16, S * S, worst))
+    assert worst < 5e-16

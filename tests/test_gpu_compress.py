@@ -50,13 +50,19 @@ def test_compressed_matches_direct_and_oracle(variant, n, fsa, B):
     direct = ctx.lnprob_batch(th)
     dA, dB = ctx.lnprob_pieces(th)
     ctx.set_option("compress", 1)
+    ctx.set_option("compress_grid", 0)
+    A, Bp = ctx.lnprob_pieces(th)
+    assert np.array_equal(Bp, dB)                                  # full grid: the integral is untouched
+    ctx.set_option("compress_grid", 1)                             # (default) FREE: the separable grid is compressed too
     got = ctx.lnprob_batch(th)
     A, Bp = ctx.lnprob_pieces(th)
-    assert np.array_equal(Bp, dB)                                  # the grid integral is untouched
     relA = np.max(np.abs(A - dA) / np.abs(dA))
+    relB = np.max(np.abs(Bp - dB) / np.abs(dB))
     rel = np.max(np.abs(got - direct) / np.abs(direct))
-    print("%s n=%d: compressed vs direct: lnprob %.2e piece A %.2e" % (variant, n, rel, relA))
-    assert rel < 1e-13 and relA < 1e-13
+    print("%s n=%d: compressed vs direct: lnprob %.2e piece A %.2e piece B %.2e" % (variant, n, rel, relA, relB))
+    assert rel < 1e-13 and relA < 1e-13 and relB < 1e-13
+    if variant == "zevol":
+        assert np.array_equal(Bp, dB)                              # no grid compression for the z-evolving model
     if n <= 10000:
         compare_rows(got, O.lnprob_batch(inp, th), inp, th, RTOL)
     for gi in (1, 2, 4, 8):                                        # every instantiated geometry
