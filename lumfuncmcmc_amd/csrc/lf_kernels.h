@@ -734,8 +734,16 @@ __device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, co
             if (j < gc.S) Tw[j] = fexp_c(fma(r[R_C1], Lj[q] - r[R_LSTAR], r[R_C0]) - PGj[q] * r[R_Q], &tab);
         }
         __syncthreads();
+        // dot product with T_w over the bin's rows, eight weights in flight at a time (a rolled loop would pay one
+        // L2 latency per row)
         double R = 0.0;
-        for (int k = 0; k < nr; ++k) R = fma(Tw[j0 + k], om[k * 16], R);
+        for (int k0 = 0; k0 < nr; k0 += 8) {
+            double o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = k0 + i < nr ? om[(k0 + i) * 16] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) R = fma(Tw[min(j0 + k0 + i, gc.S - 1)], o[i], R);
+        }
         const double Fs = field_sum_nf(kc, r, r[R_ALPHAC], u, a4, &tab);
         red[w * BLOCK + tid] = R * Fs;
     }

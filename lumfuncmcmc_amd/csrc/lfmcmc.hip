@@ -299,7 +299,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd)) != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchD = cmp ? ctd->n : 0;
-    const int nresc = cmp ? std::min(nchD, 1024) : 0;      // they leave at once unless a walker was flagged
+    // rescue workgroups leave at once unless a walker was flagged; still, each costs a dispatch slot: scale with B
+    const int nresc = cmp ? std::min(nchD, std::min(1024, std::max(128, 2 * B))) : 0;
     const bool cgrid = cmp && c->gridc.built && c->opt_compress_grid && !c->opt_skip_grid;
     const int nchB = c->opt_skip_grid ? 0 : (cgrid ? (c->gridc.nb + 15) / 16 : (c->nnodes + BLOCK - 1) / BLOCK);
     rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * nchD);
@@ -352,6 +353,13 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
             int t = 1;
             while (t < geo.twb && (int64_t)nchB * ((B + 2 * t - 1) / (2 * t)) >= want) t *= 2;
             twb = t;
+        }
+        if (cmp && nchA > 0) {
+            // the pseudo-sources are a handful of chunks: per workgroup the walker loop is a chain of dependent
+            // terms (latency, not issue), so small batches get few walkers per workgroup and many workgroups
+            int t = 1;
+            while (t < geo.tw && (int64_t)nchA * ((B + 2 * t - 1) / (2 * t)) >= 1024) t *= 2;
+            tw = t;
         }
         if (c->opt_walker_tile > 0) {
             tw = (int)std::min<int64_t>(c->opt_walker_tile, geo.tw);
