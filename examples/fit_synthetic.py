@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--nsteps", type=int, default=300)
     ap.add_argument("--fix-comp", action="store_true")
     ap.add_argument("--out", default="LFMCMCOut")
+    ap.add_argument("--compress", action="store_true", help="compressed catalogue and grid (DESIGN.md section 3.5)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     cpath = os.path.join(args.out, "synthetic_catalogue.dat")
@@ -54,7 +55,7 @@ def main():
                         phistar=synth.PHISTAR, phistar_lims=synth.PHISTAR_LIMS, Lc=synth.LC, Lh=synth.LH,
                         nwalkers=args.nwalkers, nsteps=args.nsteps, fix_sch_al=False, fix_comp=args.fix_comp,
                         min_comp_frac=0.0, Flim_lims=synth.FLIM_LIMS, alpha_lims=synth.ALPHA_LIMS,
-                        field_names=field_names, field_ind=field_ind)
+                        field_names=field_names, field_ind=field_ind, compress=args.compress)
     print("setup %.2f s for %d sources" % (time.time() - t0, len(LFmod.lum)))
     np.random.seed(3)
     LFmod.fit_model()
