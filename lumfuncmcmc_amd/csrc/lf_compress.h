@@ -39,17 +39,28 @@ struct Model {
     double piv[3];                         // ZEVOL: pivots
 };
 
-inline int ncorners(const Model& m) { return m.kind == 1 ? 8 : 25; }
+// Walkers the bound is evaluated for.  ZEVOL: the 8 corners of the (L1, L2, L3) box - the exponent's slope is
+// linear in them, so its extremes sit on corners.  FREE (sources and grid): NALPHA slopes from alpha_lo to
+// alpha_hi times `nshift` values of lF = log10(1e-17 Flim) from flim_lo to flim_hi; lF only translates the
+// function along the coordinate, so the shifts are spaced at most half a bin width apart (every stretch of the
+// function is seen by a window of this bin's width, up to half a window).
+constexpr int NALPHA = 7;
+constexpr int MAX_SHIFTS = 96;
+inline int nshifts(const Model& m, double width) {
+    const double span = std::log10(std::max(m.flim_hi, 1e-6) / std::max(std::min(m.flim_lo, m.flim_hi), 1e-6));
+    return std::max(2, std::min(MAX_SHIFTS, (int)std::ceil(span / (0.5 * width)) + 1));
+}
+inline int ncorners(const Model& m, double width) { return m.kind == 1 ? 8 : NALPHA * nshifts(m, width); }
 
 // the function of the source coordinate for prior-box corner `corner`, in long double
-inline long double feval(const Model& m, int corner, long double x) {
+inline long double feval(const Model& m, int corner, long double x, int nshift = 5) {
     if (m.kind != 1) {
-        const int ia = corner / 5, il = corner % 5;
+        const int ia = corner / nshift, il = corner % nshift;
         const long double alo = std::max(m.alpha_lo, 1e-3);
-        const long double aC = alo + (std::max<long double>(m.alpha_hi, alo) - alo) * ia / 4.0L;
-        const long double flo = std::max(m.flim_lo, 1e-6);
-        const long double Fl = flo + (std::max<long double>(m.flim_hi, flo) - flo) * il / 4.0L;
-        const long double xs = x - (log10l(Fl) - 17.0L);
+        const long double aC = alo + (std::max<long double>(m.alpha_hi, alo) - alo) * ia / (long double)(NALPHA - 1);
+        const long double flo = std::max(m.flim_lo, 1e-6), fhi = std::max<long double>(m.flim_hi, flo);
+        const long double lF = log10l(flo) + (log10l(fhi) - log10l(flo)) * il / (long double)(nshift - 1) - 17.0L;
+        const long double xs = x - lF;
         const long double num = aC * xs;
         // ln fc, fc = (1 + num / sqrt(1 + num^2)) / 2, without the cancellations of the literal form:
         // fc = 1 / (2 s (s - num)) for num < 0,  1 - fc = 1 / (2 s (s + num)) for num >= 0
@@ -84,9 +95,10 @@ inline double bin_error(const Model& m, double a, double b) {
     }
     const int M = 2 * K + 1;
     long double worst = 0.0L;
-    for (int cr = 0; cr < ncorners(m); ++cr) {
+    const int nsh = nshifts(m, b - a);
+    for (int cr = 0; cr < ncorners(m, b - a); ++cr) {
         long double f[K], c[K];
-        for (int n = 0; n < K; ++n) f[n] = feval(m, cr, xn[n]);
+        for (int n = 0; n < K; ++n) f[n] = feval(m, cr, xn[n], nsh);
         for (int k = 0; k < K; ++k) {
             long double s = 0.0L;
             for (int n = 0; n < K; ++n) s += f[n] * ct[k][n];
@@ -102,7 +114,7 @@ inline double bin_error(const Model& m, double a, double b) {
                 b1 = b0;
             }
             const long double p = t * b1 - b2 + c[0];
-            const long double fx = feval(m, cr, mid + half * t);
+            const long double fx = feval(m, cr, mid + half * t, nsh);
             emax = std::max(emax, fabsl(p - fx));
             fmin = std::min(fmin, fabsl(fx));
         }
