@@ -171,7 +171,22 @@ struct Out {
 
 // Compress one field: keys[n] (finite), wt[n] or NULL (= 1).  Appends to out.  Returns false when the bins
 // cannot be made accurate enough (the caller then leaves the option off).
-inline bool compress_field(const Model& m, const double* key, const double* wt, int64_t n, Out& out) {
+// `shared` (optional): bin edges validated once for a range that contains every field's keys (Bins below), so that
+// the fields of a catalogue do not each pay for the validation.
+struct Bins {
+    std::vector<double> edges;
+    double bound = 0.0;
+    bool ok = false;
+};
+inline Bins shared_bins(const Model& m, double lo, double hi) {
+    Bins b;
+    if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return b;
+    b.bound = make_bins(m, lo, hi, m.kind == 0 ? 0.2 : 0.04, b.edges);
+    b.ok = b.bound < HUGE_VAL;
+    return b;
+}
+
+inline bool compress_field(const Model& m, const double* key, const double* wt, int64_t n, Out& out, const Bins* shared = nullptr) {
     if (n <= 0) return true;
     double lo = key[0], hi = key[0];
     for (int64_t i = 0; i < n; ++i) {
@@ -186,9 +201,15 @@ inline bool compress_field(const Model& m, const double* key, const double* wt, 
         }
         return true;
     }
-    const double width0 = m.kind == 0 ? 0.2 : 0.04;       // refined by halving where the bound asks for it
     std::vector<double> edges;
-    const double bound = make_bins(m, lo, hi, width0, edges);
+    double bound;
+    if (shared && shared->ok && shared->edges.front() <= lo && shared->edges.back() >= hi) {
+        edges = shared->edges;
+        bound = shared->bound;
+    } else {
+        const double width0 = m.kind == 0 ? 0.2 : 0.04;   // refined by halving where the bound asks for it
+        bound = make_bins(m, lo, hi, width0, edges);
+    }
     if (!(bound < HUGE_VAL)) return false;
     out.bound = std::max(out.bound, bound);
     const int nb = (int)edges.size() - 1;

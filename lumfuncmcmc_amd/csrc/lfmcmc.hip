@@ -440,9 +440,16 @@ int build_compressed(lf_ctx* c) {
     lfc::Out out;
     CompressedCat cc;
     cc.field_ind.assign(1, 0);
+    // one validated set of bins for the whole catalogue's coordinate range, shared by the fields
+    double klo = HUGE_VAL, khi = -HUGE_VAL;
+    for (int64_t i = 0; i < N; ++i) {
+        klo = std::fmin(klo, key[(size_t)i]);
+        khi = std::fmax(khi, key[(size_t)i]);
+    }
+    const lfc::Bins bins = lfc::shared_bins(m, klo, khi);
     for (int f = 0; f < c->kc.nf; ++f) {
         const int64_t lo = c->field_ind[f], hi = c->field_ind[f + 1];
-        if (!lfc::compress_field(m, key.data() + lo, wt.empty() ? nullptr : wt.data() + lo, hi - lo, out)) {
+        if (!lfc::compress_field(m, key.data() + lo, wt.empty() ? nullptr : wt.data() + lo, hi - lo, out, &bins)) {
             c->err = "compress: the catalogue of field " + std::to_string(f) + " cannot be compressed to the error bound "
                      "(non-finite coordinate, or a prior box the bins cannot resolve)";
             return LF_ERR_ARG;
