@@ -124,10 +124,12 @@ inline double bin_error(const Model& m, double a, double b) {
             const long double fm = std::max(fmin, (long double)GRID_FLOOR);
             if (!std::isfinite((double)emax)) return HUGE_VAL;
             worst = std::max(worst, emax / (fm * (1.0L + fabsl(logl(fm)))));
+            if (worst > COMPRESS_TOL) return (double)worst;
             continue;
         }
         if (!(fmin > 0.0L) || !std::isfinite((double)emax)) return HUGE_VAL;
         worst = std::max(worst, emax / fmin);
+        if (worst > COMPRESS_TOL) return (double)worst;      // the bin will be halved: no need for the other walkers
     }
     return (double)worst;
 }
