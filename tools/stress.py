@@ -33,6 +33,30 @@ chk = O.lnprob_batch(inp, big[19990:19993])
 assert np.max(np.abs(out[19990:19993] / chk - 1)) < 1e-12
 c.close()
 
+# compressed catalogue + grid: create / build / destroy repeatedly, toggling between the paths, a long chain
+inp = make_inputs("free", 200000, seed=1)
+free2 = torch.cuda.mem_get_info()[0]
+for i in range(10):
+    c = LFContext(inp)
+    a = c.lnprob_batch(th)
+    c.set_option("compress", 1)
+    b = c.lnprob_batch(th)
+    c.set_option("compress", 0)
+    assert np.array_equal(c.lnprob_batch(th), a) and np.allclose(a, b, rtol=1e-13, atol=0)
+    c.close()
+torch.cuda.synchronize()
+print("compress build/destroy x10: device memory delta %.1f MB" % ((free2 - torch.cuda.mem_get_info()[0]) / 1e6))
+c = LFContext(inp)
+c.set_option("compress", 1)
+ds = DeviceEnsembleSampler(c, 256, seed=6, capacity=5000)
+t = time.perf_counter(); ds.run_mcmc(synth.walkers("free", 256, seed=7), 5000); dt = time.perf_counter() - t
+last = ds.chain[:, -1, :]
+c.set_option("compress", 0)
+assert np.allclose(c.lnprob_batch(last), ds.lnprobability[:, -1], rtol=1e-12, atol=0)
+print("compressed: 5000 steps x 256 walkers at N=200000: %.2f s (%.1f us/step), acceptance %.2f; final lnprob = direct lnprob of the final positions"
+      % (dt, dt / 5000 * 1e6, ds.acceptance_fraction.mean()))
+ds.close(); c.close()
+
 inp = make_inputs("fixcomp", 5000, seed=4)
 c = LFContext(inp)
 ds = DeviceEnsembleSampler(c, 64, seed=5, capacity=20000)
