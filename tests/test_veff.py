@@ -83,3 +83,19 @@ def test_set_median_fit_and_table_flow():
     o.add_fitinfo_to_table(percentiles)
     row = o.table[-1]
     assert abs(row[3] - 42.5) < 0.01 and row[1] < row[3] < row[5]          # L*: 5th < 50th < 95th
+
+
+def test_vectorised_max_redshift_equals_the_per_source_fsolve():
+    """V.getMaxz (VmaxLumFunc.py:761-777) solves 4 pi DL(z)^2 fmin = L with one fsolve per source; the build
+    inverts DL for all sources at once.  Same roots (the reference's to its own tolerance)."""
+    from lumfuncmcmc_amd import veff
+    from lumfuncmcmc_amd.cosmology import cosmo
+    rng = np.random.default_rng(0)
+    L = 10 ** rng.uniform(41.0, 43.5, 150)
+    fm = 10 ** rng.uniform(-17.5, -16.3, 150)
+    z0 = veff.max_redshift_fsolve(L, fm, cosmo)
+    z1 = veff.max_redshift(L, fm, cosmo)
+    np.testing.assert_allclose(z1, z0, rtol=1e-9)
+    res = 4 * np.pi * (cosmo.luminosity_distance(z1) * veff.MPC_CM_EXACT) ** 2 * fm / L - 1
+    assert np.max(np.abs(res)) < 1e-13
+    assert np.isnan(veff.max_redshift(np.array([1e42, np.nan]), np.array([1e-17, 1e-17]), cosmo)[1])
