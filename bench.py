@@ -32,6 +32,12 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU instruction = 1.  (The survey's nominal weights - exp/log = 40 flops - would put the same
 # run at ~100 % of peak; DESIGN.md section 4 explains why that figure is not used.)
 FLOPS_PER_TERM = {"free": 54.0, "zevol": 27.0, "fixcomp": 0.0}
+# free variant: terms of (walker, chunk) pairs whose every source has f / f_tau > 37.5 - the decay factor is exactly
+# 1.0 in binary64 - run term_free_noexp (lf_kernels.h): 30 executed flops, 95 issue cycles (profiles/isa_mix.py: the
+# walker loop holds both forms, 84.1 flops and 269 cycles together).  bench.py counts which pairs of the timed
+# workload take it (noexp_terms below) so that `achieved` stays the executed count.
+FLOPS_PER_TERM_NOEXP = 30.0
+CYCLES_PER_TERM_NOEXP = 95.0
 # issue cycles one wave spends per term (fp64 VALU 4, v_rcp/v_rsq_f64 16, 32-bit VALU 2.5; measured
 # rates in profiles/r01_ubench.txt), for the issue-utilisation figure
 CYCLES_PER_TERM = {"free": 174.0, "zevol": 81.0, "fixcomp": 0.0}
@@ -100,6 +106,36 @@ def cpu_baseline_allcores(model, theta, nthreads):
             "sample": "%d theta rows of the timed workload over %d OpenMP threads, %.1f s, plain-C scalar loop" % (len(rows), nthreads, dt)}
 
 
+def noexp_terms(model, blocks, chunk):
+    """(walker, source) terms per launch that take term_free_noexp, averaged over the theta blocks of the timed
+    workload: the kernel's own test, per (walker, chunk of `chunk` flux-sorted sources of a field), on the host."""
+    from lumfuncmcmc_amd.capi import log_flux
+    ki = model.kernel_inputs()
+    if ki["variant"] != "free":
+        return 0.0
+    logf = log_flux(np.asarray(ki["lum"]), np.asarray(ki["DLz"]))
+    fi = np.asarray(ki["field_ind"])
+    nf = len(fi) - 1
+    a = (2.0 * ki["fcmin"] - 1.0) ** 2
+    ratio = abs(a / (1.0 - a))
+    k0 = 2 if ki["fix_sch_al"] else 3
+    total = 0.0
+    for th in blocks:
+        aC = th[:, -1]
+        b = -np.sqrt(ratio / aC ** 2)
+        for f in range(nf):
+            x = np.sort(logf[fi[f]:fi[f + 1]])
+            first = x[::chunk]
+            lens = np.diff(np.append(np.arange(0, x.size, chunk), x.size))
+            Fl = th[:, k0 + f]
+            lF = np.log10(1.0e-17 * Fl)
+            V = 1.0 / (Fl * 10.0 ** b)
+            ok = (aC[:, None] > 0) & (aC[:, None] * (first[None, :] - lF[:, None]) >= 0) & \
+                 (10.0 ** (first[None, :] + 17.0) * V[:, None] > 37.5)
+            total += float((ok * lens[None, :]).sum())
+    return total / len(blocks)
+
+
 def compressed_leg(ctx, step, fence, direct_out, steps, W):
     import torch
     t0 = time.perf_counter()
@@ -154,6 +190,7 @@ def main():
     ap.add_argument("--walker-tile", type=int, default=0)
     ap.add_argument("--no-taper", action="store_true", help="(default) single pass over the catalogue")
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
+    ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")
@@ -206,6 +243,8 @@ def main():
         ctx.set_option("taper", 1)
     if args.compress:
         ctx.set_option("compress", 1)
+    if args.no_specialise:
+        ctx.set_option("specialise", 0)
     ndim = ctx.ndim
     from lumfuncmcmc_amd import synth
     # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
@@ -260,7 +299,16 @@ def main():
         terms = float(args.nsrc) * half                                   # (walker, source) terms per launch
         S, nf = model.size_ln, len(model.Flim)
         grid_flops = float(half) * S * S * (FLOPS_PER_NODE[args.variant] + nf * FLOPS_PER_NODE_FIELD[args.variant])
-        alg_flops = terms * FLOPS_PER_TERM[args.variant] + grid_flops
+        t_noexp = 0.0
+        if args.variant == "free" and not args.no_specialise and not args.compress:
+            used = sorted({(2 * i) % nblk for i in range(args.steps)} | {(2 * i + 1) % nblk for i in range(args.steps)})
+            # sources per chunk = 256 x the geometry's sources per lane (lfmcmc.hip: GEOS, pick_geometry)
+            st_of = [8, 2, 8, 8, 4, 4, 6, 4, 2]
+            auto_big = -(-args.nsrc // 2048) * -(-half // 16) >= 1024
+            st = st_of[args.geometry] if args.geometry >= 0 else (8 if auto_big else 2)
+            t_noexp = noexp_terms(model, [theta_all[j, rank * half:(rank + 1) * half] for j in used], 256 * st)
+        src_flops = (terms - t_noexp) * FLOPS_PER_TERM[args.variant] + t_noexp * FLOPS_PER_TERM_NOEXP
+        alg_flops = src_flops + grid_flops
         alg_bytes = args.nsrc * BYTES_PER_SOURCE[args.variant] + half * 8 * (ndim + 1)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -276,10 +324,12 @@ def main():
                     "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
                     "terms_per_launch": terms, "flops_per_term_executed": FLOPS_PER_TERM[args.variant],
-                    "flops_per_launch": {"source_terms": terms * FLOPS_PER_TERM[args.variant], "grid_integral": grid_flops},
+                    "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
+                    "noexp_terms_per_launch": t_noexp, "flops_per_term_noexp": FLOPS_PER_TERM_NOEXP,
                     "terms_per_s": terms / (avg_ms * 1e-3),
                     # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the term loop needs
-                    "valu_issue_frac_at_2p4GHz": term_waves_per_s * CYCLES_PER_TERM[args.variant] / (1024 * 2.4e9),
+                    "valu_issue_frac_at_2p4GHz": ((terms - t_noexp) * CYCLES_PER_TERM[args.variant] + t_noexp * CYCLES_PER_TERM_NOEXP)
+                                                 / 64.0 / (avg_ms * 1e-3) / (1024 * 2.4e9),
                     "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
                     "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items() if n != "unused"}}

@@ -138,6 +138,8 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * With it, FREE contexts whose integration grid is separable (every redshift column has the same luminosity nodes:
  * min_comp_frac = 0) also take piece B over ~40 x 16 shared flux nodes per field instead of the S^2 lattice points
  * (same bound; "compress_grid" = 0 keeps the full grid).
+ * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
+ * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
  * "graph": 1 lets lf_sampler_run replay one captured hipGraph per ensemble step instead of six launches (same
  * kernels, same random numbers, same chain; the step index then lives in device memory); 0 (default) = plain
  * launches - on ROCm 7.0 the replay gains <= 5 % and shows a sporadic ~30 ms stall, see DESIGN.md.

@@ -43,6 +43,7 @@ enum { Z_AL = 0, Z_BL = 1, Z_CL = 2, Z_AP = 3, Z_BP = 4, Z_CP = 5, Z_C1 = 6 };
 
 struct KConst {
     int variant, fix_sch_al, nf, S, ndim;
+    int specialise;           // 1: chunk-level term specialisation (term_free_noexp); 0 for A/B runs
     double lnom0_src[MAXF];   // ln(trunc(Omega_0[f]) / sqarcsec)   (int-truncated, lumfuncmcmc.py:285)
     double om0_grid[MAXF];    // Omega_0[f] / sqarcsec              (float, lumfuncmcmc.py:375)
     double fc_ratio;          // |a / (1 - a)|, a = (2 fcmin - 1)^2 (VmaxLumFunc.py:164-165)
@@ -388,6 +389,28 @@ __device__ __forceinline__ double term_free_fast(const WFree& w, double logf, do
     return lnfc * ((Z * sd) * Z);
 }
 
+// The catalogue is sorted by flux inside each field (lfmcmc.hip: build), so a chunk's first source is its
+// faintest, and two wave-uniform facts about a (walker, chunk) pair select a cheaper form of the same term:
+//   UPPER   alpha_C (logf_min - lF) >= 0: every source of the chunk is at or above the walker's 50 % flux, fc in
+//           [1/2, 1]: the log needs no exponent handling (flog_half_upper)
+//   NOEXP   U_min V > 37.5 = 54.1 ln 2: e^(-f/f_tau) < 2^-54 for every source, so 1 - e^(-f/f_tau) is exactly 1.0
+//           in binary64 - the value the general form computes too - and the term is ln(fc): no exp, no 1/d
+__device__ __forceinline__ double term_free_upper(const WFree& w, double logf, double U,
+                                                  const MathTables* __restrict__ tab) {
+    const double num = fma(w.alphaC, logf, w.cA);
+    const double s = fma(num, num, 1.0);
+    const double d = 1.0 - fexp_neg(U * w.V, tab);
+    const double sd = s * d;
+    const double Z = frsqrt(sd * d);
+    const double lnfc = flog_half_upper(fma(num, Z * d, 1.0), tab);
+    return lnfc * ((Z * sd) * Z);
+}
+__device__ __forceinline__ double term_free_noexp(const WFree& w, double logf, const MathTables* __restrict__ tab) {
+    const double num = fma(w.alphaC, logf, w.cA);
+    const double s = fma(num, num, 1.0);
+    return flog_half_upper(fma(num, frsqrt(s), 1.0), tab);
+}
+
 __device__ __forceinline__ double term_free_careful(const WFree& w, double lum, double logf, double P, double U) {
     const double NEG_INF = -__builtin_huge_val();
     const double v = P * w.Q;
@@ -460,6 +483,9 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     // one item: catalogue chunk c x walkers w0 .. w0+nw-1 (nw <= TW, which sizes the LDS buffer)
     const int tid = threadIdx.x;
     const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
+    // FREE: sources are sorted by flux inside a field, the chunk's first is its faintest (NaN fluxes sort last and
+    // put the field on the careful path anyway)
+    const double a1_first = VARIANT == LF_FREE ? sa.a1[s0] : 0.0, u_first = VARIANT == LF_FREE ? sa.U[s0] : 0.0;
 
     if (VARIANT == LF_FIXCOMP) {
         // piece A is closed-form (wbase): unless one of the tile's walkers needs the per-term underflow
@@ -520,10 +546,21 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 nxA = rn[R_ALPHAC];
                 nxC = rn[R_CA + fld];
                 nxV = rn[R_V + fld];
+                // chunk-level facts (the first source of a chunk is its faintest), see term_free_upper / _noexp
+                const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
+                const bool noexp = upper && u_first * wf.V > 37.5;
+                if (noexp) {
 #pragma unroll
-                for (int k = 0; k < ST; ++k) {
-                    const double term = term_free_fast(wf, a1[k], uu[k], &tab);
-                    acc = CMP ? fma(term, wgt[k], acc) : acc + term;
+                    for (int k = 0; k < ST; ++k) {
+                        const double term = term_free_noexp(wf, a1[k], &tab);
+                        acc = CMP ? fma(term, wgt[k], acc) : acc + term;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < ST; ++k) {
+                        const double term = term_free_fast(wf, a1[k], uu[k], &tab);
+                        acc = CMP ? fma(term, wgt[k], acc) : acc + term;
+                    }
                 }
             } else if (VARIANT == LF_FIXCOMP) {
                 // nothing left per source: piece A is the closed form in wbase

@@ -92,6 +92,21 @@ __device__ __forceinline__ double flog_half(double w, const MathTables* __restri
     return hi_part + fma(p, r2, r);
 }
 
+// ln(w / 2) for w in [1, 2] (flux at or above the 50 % limit): the exponent of w/2 is known, so no exponent
+// extraction, no int -> double conversion, and the argument is its own mantissa.  w = 2 exactly (fc = 1 to
+// rounding) is nudged one ulp down: ln gives -1.1e-16 instead of 0.
+__device__ __forceinline__ double flog_half_upper(double w, const MathTables* __restrict__ mt) {
+    const double m = fmin(w, 1.9999999999999998);
+    const int j = (__double2hiint(m) >> 12) & 0xff;
+    const double2 t = mt->logt[j];
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, 0.2, -0.25);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -0.5);
+    const double r2 = r * r;
+    return (t.y - LF_LN2) + fma(p, r2, r);
+}
+
 // 1/sqrt(s), s >= 1: v_rsq_f64 seed (2^-24, measured) + one cubic step (error ~ e^3)
 __device__ __forceinline__ double frsqrt(double s) {
     const double z0 = __builtin_amdgcn_rsq(s);

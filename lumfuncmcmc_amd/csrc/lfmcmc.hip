@@ -132,6 +132,27 @@ int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<i
             fl.push_back(f);
         }
     }
+    // Chunk order = a fixed stride permutation of the natural (field by field, faint to bright) order: lf_main
+    // deals contiguous runs of chunk indices to the 8 XCDs, and with the catalogue sorted by flux a natural order
+    // would hand one XCD only faint chunks (full-cost terms) and another only bright ones (term_free_noexp).
+    {
+        const size_t n = st.size();
+        if (n > 8) {
+            size_t stride = (size_t)(0.6180339887 * (double)n) | 1;
+            auto gcd = [](size_t a, size_t b) { while (b) { const size_t t_ = a % b; a = b; b = t_; } return a; };
+            while (gcd(stride, n) != 1) stride += 2;
+            std::vector<int> st2(n), ln2(n), fl2(n);
+            for (size_t i = 0; i < n; ++i) {
+                const size_t j = (i * stride) % n;
+                st2[i] = st[j];
+                ln2[i] = ln[j];
+                fl2[i] = fl[j];
+            }
+            st.swap(st2);
+            ln.swap(ln2);
+            fl.swap(fl2);
+        }
+    }
     ChunkTable t;
     t.n = (int)st.size();
     int rc;
@@ -454,6 +475,21 @@ int build_compressed(lf_ctx* c) {
                      "(non-finite coordinate, or a prior box the bins cannot resolve)";
             return LF_ERR_ARG;
         }
+        // in order of the coordinate inside the field, like the real catalogue (bins that kept their sources hold
+        // them in catalogue order): a chunk's first pseudo-source is its faintest
+        {
+            const size_t a = (size_t)cc.field_ind.back(), b = out.node.size();
+            std::vector<size_t> idx(b - a);
+            for (size_t i = 0; i < idx.size(); ++i) idx[i] = a + i;
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return out.node[x] < out.node[y]; });
+            std::vector<double> nn(idx.size()), ww(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) {
+                nn[i] = out.node[idx[i]];
+                ww[i] = out.weight[idx[i]];
+            }
+            std::copy(nn.begin(), nn.end(), out.node.begin() + (std::ptrdiff_t)a);
+            std::copy(ww.begin(), ww.end(), out.weight.begin() + (std::ptrdiff_t)a);
+        }
         cc.field_ind.push_back((int64_t)out.node.size());
     }
     cc.n = (int64_t)out.node.size();
@@ -541,6 +577,7 @@ int build(lf_ctx* c, const lf_desc* d) {
     KConst& kc = c->kc;
     kc.variant = d->variant;
     kc.fix_sch_al = d->fix_sch_al ? 1 : 0;
+    kc.specialise = 1;
     kc.nf = nf;
     kc.S = S;
     if (d->variant == LF_FREE) kc.ndim = 2 + (kc.fix_sch_al ? 0 : 1) + nf + 1;
@@ -569,22 +606,33 @@ int build(lf_ctx* c, const lf_desc* d) {
     c->nnodes = S * S;
     c->field_ind.assign(d->field_ind, d->field_ind + nf + 1);
 
-    // ---- per-source tables
-    std::vector<double> a1(N), P(N), U(N);
+    // ---- per-source tables.  FREE: the sources of a field are put in order of flux (the layout is ours to choose; a
+    // sum over sources does not care), so that a chunk's first source is its faintest and the kernels can pick
+    // cheaper forms of the term per (walker, chunk) - see term_free_upper / term_free_noexp.  NaN fluxes go last.
+    std::vector<int64_t> perm((size_t)N);
+    for (int64_t i = 0; i < N; ++i) perm[(size_t)i] = i;
+    if (d->variant == LF_FREE)
+        for (int f = 0; f < nf; ++f)
+            std::stable_sort(perm.begin() + d->field_ind[f], perm.begin() + d->field_ind[f + 1], [&](int64_t a, int64_t b) {
+                const double x = d->logf[a], y = d->logf[b];
+                return std::isnan(y) ? !std::isnan(x) : x < y;
+            });
+    std::vector<double> lumv(N), a1(N), P(N), U(N);
+    for (int64_t i = 0; i < N; ++i) lumv[(size_t)i] = d->lum[perm[(size_t)i]];
     for (int64_t i = 0; i < N; ++i) {
-        const double lum = d->lum[i];
+        const double lum = lumv[(size_t)i];
         if (d->variant == LF_FREE) {
-            a1[i] = d->logf[i];
+            a1[i] = d->logf[perm[(size_t)i]];
             P[i] = std::pow(10.0, lum - LF_LREF);
-            U[i] = std::pow(10.0, d->logf[i] - LF_FREF);
+            U[i] = std::pow(10.0, d->logf[perm[(size_t)i]] - LF_FREF);
         } else if (d->variant == LF_FIXCOMP) {
-            a1[i] = std::log(d->om_arr[i]);
+            a1[i] = std::log(d->om_arr[perm[(size_t)i]]);
             P[i] = std::pow(10.0, lum - LF_LREF);
             U[i] = 0.0;
         } else {
-            a1[i] = d->z[i];
-            P[i] = std::log(d->om_arr[i]);
-            U[i] = d->z[i] * d->z[i];
+            a1[i] = d->z[perm[(size_t)i]];
+            P[i] = std::log(d->om_arr[perm[(size_t)i]]);
+            U[i] = d->z[perm[(size_t)i]] * d->z[perm[(size_t)i]];
         }
     }
     // per-field extremes for the mode classification in lf_prepare
@@ -600,27 +648,27 @@ int build(lf_ctx* c, const lf_desc* d) {
         bool nan = false;
         long double slc = 0.0L, sp = 0.0L, som = 0.0L, sz = 0.0L, sz2 = 0.0L;
         for (int64_t i = lo; i < hi; ++i) {
-            const double lum = d->lum[i];
+            const double lum = lumv[(size_t)i];
             slc += (long double)(lum - LF_LREF);
             if (d->variant != LF_ZEVOL) sp += (long double)P[i];
             if (d->variant == LF_FIXCOMP) som += (long double)a1[i];
             if (d->variant == LF_ZEVOL) {
                 som += (long double)P[i];
-                sz += (long double)d->z[i];
+                sz += (long double)d->z[perm[(size_t)i]];
                 sz2 += (long double)U[i];             // the rounded z_i^2 the kernels use
             }
             lmin = std::fmin(lmin, lum);
             lmax = std::fmax(lmax, lum);
             nan = nan || std::isnan(lum);
             if (d->variant != LF_ZEVOL) pmax = std::fmax(pmax, P[i]);
-            const double a = d->variant == LF_FREE ? d->logf[i] : (d->variant == LF_FIXCOMP ? a1[i] : P[i]);
+            const double a = d->variant == LF_FREE ? a1[i] : (d->variant == LF_FIXCOMP ? a1[i] : P[i]);
             amin = std::fmin(amin, a);
             amax = std::fmax(amax, a);
             nan = nan || std::isnan(a);
             if (d->variant == LF_ZEVOL) {
-                zlo = std::fmin(zlo, d->z[i]);
-                zhi = std::fmax(zhi, d->z[i]);
-                nan = nan || std::isnan(d->z[i]);
+                zlo = std::fmin(zlo, d->z[perm[(size_t)i]]);
+                zhi = std::fmax(zhi, d->z[perm[(size_t)i]]);
+                nan = nan || std::isnan(d->z[perm[(size_t)i]]);
             }
         }
         if (nan) amin = -HUGE_VAL;                 // NaN input: force the careful path
@@ -639,7 +687,7 @@ int build(lf_ctx* c, const lf_desc* d) {
         kc.sz2[f] = (double)sz2;
     }
     int rc;
-    if ((rc = upload(c, &c->d_lum, d->lum, (size_t)N)) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_lum, lumv.data(), (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a1, a1.data(), (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_P, P.data(), (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_U, U.data(), (size_t)N)) != LF_OK) return rc;
@@ -892,6 +940,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             if (rc != LF_OK) return rc;
         }
         c->opt_compress = value != 0;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "specialise") == 0) {
+        c->kc.specialise = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "compress_grid") == 0) {

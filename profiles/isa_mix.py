@@ -76,6 +76,9 @@ def main():
             other = sum(fp64.values()) - fma
             ints = sum(v for k, v in c.items() if k.startswith("v_") and "f64" not in k)
             lds = sum(v for k, v in c.items() if k.startswith("ds_read"))
+            if variant == 0 and c.get("v_rsq_f64_e32", 0) == 2 * st:
+                print("   (next loop: the walker loop of the free variant holds BOTH forms of the term - the general one, "
+                      "54 flops / 174 cycles, and term_free_noexp: the rest)")
             print("lf_main<variant %d, ST %d>  loop of %d lines, per item (term or grid node-field):" % (variant, st, b - a))
             print("   fp64 fma %.2f   other fp64 VALU %.2f   32-bit VALU %.2f   LDS reads %.2f" % (fma / st, other / st, ints / st, lds / st))
             print("   executed fp64 flops/term (fma = 2, other = 1): %.1f" % ((2 * fma + other) / st))
