@@ -274,10 +274,14 @@ def main():
     ctx.kernel_times()                      # clear
     ctx.set_profiling(args.profile_level)
     t0 = time.perf_counter()
+    dbg = []
     for i in range(args.steps):
         out = step(i)
+        dbg.append(time.perf_counter() - t0)
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get("LF_BENCH_DEBUG"):
+        print("debug: host time after each step (ms):", " ".join("%.2f" % (x * 1e3) for x in dbg[:8]), "fence done %.2f" % (dt * 1e3), file=sys.stderr)
     ctx.set_profiling(0)
     kt = ctx.kernel_times()
     if world > 1 or args.force_collective:

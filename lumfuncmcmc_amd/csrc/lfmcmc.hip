@@ -132,21 +132,32 @@ int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<i
             fl.push_back(f);
         }
     }
-    // Chunk order = a fixed stride permutation of the natural (field by field, faint to bright) order: lf_main
-    // deals contiguous runs of chunk indices to the 8 XCDs, and with the catalogue sorted by flux a natural order
-    // would hand one XCD only faint chunks (full-cost terms) and another only bright ones (term_free_noexp).
+    // Chunk order.  lf_main deals contiguous runs of chunk indices to the 8 XCDs (in dispatch order inside each run),
+    // and with the catalogue sorted by flux a chunk's cost depends on its rank in its field (bright chunks run
+    // term_free_noexp for most walkers).  So: deal the chunks round-robin into 8 groups (every group gets the same
+    // mix of ranks and fields: natural order would hand one XCD only full-cost chunks), and inside a group put the
+    // faint, expensive chunks first - longest first keeps the drain of the launch short.
     {
         const size_t n = st.size();
         if (n > 8) {
-            size_t stride = (size_t)(0.6180339887 * (double)n) | 1;
-            auto gcd = [](size_t a, size_t b) { while (b) { const size_t t_ = a % b; a = b; b = t_; } return a; };
-            while (gcd(stride, n) != 1) stride += 2;
+            std::vector<size_t> rank(n);                  // rank of the chunk inside its field (natural order is field-major)
+            for (size_t i = 0, r = 0; i < n; ++i) {
+                r = (i > 0 && fl[i] == fl[i - 1]) ? r + 1 : 0;
+                rank[i] = r;
+            }
+            std::vector<size_t> order;
+            order.reserve(n);
+            for (size_t g = 0; g < 8; ++g) {
+                std::vector<size_t> grp;
+                for (size_t i = g; i < n; i += 8) grp.push_back(i);
+                std::stable_sort(grp.begin(), grp.end(), [&](size_t a, size_t b) { return rank[a] < rank[b]; });
+                order.insert(order.end(), grp.begin(), grp.end());
+            }
             std::vector<int> st2(n), ln2(n), fl2(n);
             for (size_t i = 0; i < n; ++i) {
-                const size_t j = (i * stride) % n;
-                st2[i] = st[j];
-                ln2[i] = ln[j];
-                fl2[i] = fl[j];
+                st2[i] = st[order[i]];
+                ln2[i] = ln[order[i]];
+                fl2[i] = fl[order[i]];
             }
             st.swap(st2);
             ln.swap(ln2);
