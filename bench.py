@@ -190,7 +190,7 @@ def main():
     ap.add_argument("--walker-tile", type=int, default=0)
     ap.add_argument("--no-taper", action="store_true", help="(default) single pass over the catalogue")
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
-    ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
+    ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation (compare lf_main times: in this mode a one-off ~40 ms host stall of unknown origin lands in the timed loop)")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")
