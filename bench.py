@@ -37,6 +37,7 @@ FLOPS_PER_TERM = {"free": 54.0, "zevol": 27.0, "fixcomp": 0.0}
 # walker loop holds both forms, 84.1 flops and 269 cycles together).  bench.py counts which pairs of the timed
 # workload take it (noexp_terms below) so that `achieved` stays the executed count.
 FLOPS_PER_TERM_NOEXP = 30.0
+SETTLE_STEPS = 20                 # untimed steps after the W warm-up steps, see main()
 CYCLES_PER_TERM_NOEXP = 95.0
 # issue cycles one wave spends per term (fp64 VALU 4, v_rcp/v_rsq_f64 16, 32-bit VALU 2.5; measured
 # rates in profiles/r01_ubench.txt), for the issue-utilisation figure
@@ -269,6 +270,11 @@ def main():
     if side is not None:
         torch.cuda.set_stream(side)
     for i in range(args.warmup):
+        out = step(i)
+    # settle: a few more untimed steps.  On this stack one launch early in a process's life can block the host for
+    # ~40 ms (seen at about the 8th call after start-up, position depending on what ran before - cause not found);
+    # the requested warm-up steps may be too few to be past it.
+    for i in range(SETTLE_STEPS):
         out = step(i)
     fence()
     ctx.kernel_times()                      # clear
