@@ -271,9 +271,10 @@ def main():
         torch.cuda.set_stream(side)
     for i in range(args.warmup):
         out = step(i)
-    # settle: a few more untimed steps.  On this stack one launch early in a process's life can block the host for
-    # ~40 ms (seen at about the 8th call after start-up, position depending on what ran before - cause not found);
-    # the requested warm-up steps may be too few to be past it.
+    # settle: a few more untimed steps (clocks, caches, allocator pools) after whatever warm-up was asked for.
+    # (Known and not understood: when any lf_set_option call was made before - i.e. with the A/B flags of this
+    # script, never in the default run - the first timed step can block the host for ~40 ms; it goes away when the
+    # calls are instrumented, so it is timing-sensitive runtime behaviour.  Compare lf_main times in A/B runs.)
     for i in range(SETTLE_STEPS):
         out = step(i)
     fence()
