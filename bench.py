@@ -138,6 +138,7 @@ def noexp_terms(model, blocks, chunk):
 
 
 def compressed_leg(ctx, step, fence, direct_out, steps, W):
+    import gc
     import torch
     t0 = time.perf_counter()
     ctx.set_option("compress", 1)
@@ -145,11 +146,14 @@ def compressed_leg(ctx, step, fence, direct_out, steps, W):
     for i in range(3):
         out = step(i)
     fence()
+    gc.collect()
+    gc.disable()                                    # as in main(): no collector pause inside a timed window
     t0 = time.perf_counter()
     for i in range(steps):
         out = step(i)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     rel = float(torch.max(torch.abs(out[0] - direct_out[0]) / torch.abs(direct_out[0])).item())
     res = {"value": W * steps / dt, "unit": "walker-lnprob evals/s", "ms_per_step": dt / steps * 1e3,
            "build_s": build_s, "max_rel_diff_vs_direct": rel,
@@ -191,7 +195,7 @@ def main():
     ap.add_argument("--walker-tile", type=int, default=0)
     ap.add_argument("--no-taper", action="store_true", help="(default) single pass over the catalogue")
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
-    ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation (compare lf_main times: in this mode a one-off ~40 ms host stall of unknown origin lands in the timed loop)")
+    ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")
@@ -271,15 +275,17 @@ def main():
         torch.cuda.set_stream(side)
     for i in range(args.warmup):
         out = step(i)
-    # settle: a few more untimed steps (clocks, caches, allocator pools) after whatever warm-up was asked for.
-    # (Known and not understood: when any lf_set_option call was made before - i.e. with the A/B flags of this
-    # script, never in the default run - the first timed step can block the host for ~40 ms; it goes away when the
-    # calls are instrumented, so it is timing-sensitive runtime behaviour.  Compare lf_main times in A/B runs.)
+    # settle: a few more untimed steps (clocks, caches, allocator pools) after whatever warm-up was asked for
     for i in range(SETTLE_STEPS):
         out = step(i)
     fence()
     ctx.kernel_times()                      # clear
     ctx.set_profiling(args.profile_level)
+    # no interpreter pauses inside the timed window: with torch imported a full collection walks ~10^6 objects
+    # (40-80 ms, and whether one falls into the window depends on how many objects the flags allocated before)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     dbg = []
     for i in range(args.steps):
@@ -287,6 +293,7 @@ def main():
         dbg.append(time.perf_counter() - t0)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if os.environ.get("LF_BENCH_DEBUG"):
         print("debug: host time after each step (ms):", " ".join("%.2f" % (x * 1e3) for x in dbg[:8]), "fence done %.2f" % (dt * 1e3), file=sys.stderr)
     ctx.set_profiling(0)
