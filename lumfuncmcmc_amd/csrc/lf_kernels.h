@@ -390,21 +390,12 @@ __device__ __forceinline__ double term_free_fast(const WFree& w, double logf, do
 }
 
 // The catalogue is sorted by flux inside each field (lfmcmc.hip: build), so a chunk's first source is its
-// faintest, and two wave-uniform facts about a (walker, chunk) pair select a cheaper form of the same term:
-//   UPPER   alpha_C (logf_min - lF) >= 0: every source of the chunk is at or above the walker's 50 % flux, fc in
-//           [1/2, 1]: the log needs no exponent handling (flog_half_upper)
-//   NOEXP   U_min V > 37.5 = 54.1 ln 2: e^(-f/f_tau) < 2^-54 for every source, so 1 - e^(-f/f_tau) is exactly 1.0
-//           in binary64 - the value the general form computes too - and the term is ln(fc): no exp, no 1/d
-__device__ __forceinline__ double term_free_upper(const WFree& w, double logf, double U,
-                                                  const MathTables* __restrict__ tab) {
-    const double num = fma(w.alphaC, logf, w.cA);
-    const double s = fma(num, num, 1.0);
-    const double d = 1.0 - fexp_neg(U * w.V, tab);
-    const double sd = s * d;
-    const double Z = frsqrt(sd * d);
-    const double lnfc = flog_half_upper(fma(num, Z * d, 1.0), tab);
-    return lnfc * ((Z * sd) * Z);
-}
+// faintest, and one wave-uniform fact about a (walker, chunk) pair selects a cheaper form of the same term:
+//   U_min V > 37.5 = 54.1 ln 2  =>  e^(-f/f_tau) < 2^-54 for every source of the chunk, so 1 - e^(-f/f_tau) is
+//   exactly 1.0 in binary64 - the value the general form computes too - and the term is ln(fc): no exp, no 1/d.
+// Such sources are also above the walker's 50 % flux (alpha_C (logf - lF) >= 0 is tested with it), fc in [1/2, 1],
+// and the log needs no exponent handling (flog_half_upper).  (A third form - exponent-free log, exponential kept -
+// raised the kernel to 145 VGPRs and 3 waves/SIMD: dropped.)
 __device__ __forceinline__ double term_free_noexp(const WFree& w, double logf, const MathTables* __restrict__ tab) {
     const double num = fma(w.alphaC, logf, w.cA);
     const double s = fma(num, num, 1.0);
@@ -546,7 +537,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 nxA = rn[R_ALPHAC];
                 nxC = rn[R_CA + fld];
                 nxV = rn[R_V + fld];
-                // chunk-level facts (the first source of a chunk is its faintest), see term_free_upper / _noexp
+                // chunk-level facts (the first source of a chunk is its faintest), see term_free_noexp
                 const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
                 const bool noexp = upper && u_first * wf.V > 37.5;
                 if (noexp) {
@@ -817,7 +808,6 @@ struct Tiling {
 // per-term checks; bitwise when the direct path runs with the same chunk size).
 struct Rescue {
     SrcArrays sd;
-    const int* wstat;
     const int* slow_list;       // walkers flagged STAT_SLOW by lf_prepare, in arrival order
     const int* slow_count;      // how many
     double* partR;

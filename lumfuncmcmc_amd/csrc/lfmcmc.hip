@@ -366,7 +366,6 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         rs.sd.chunk_start = ctd->d_start;
         rs.sd.chunk_len = ctd->d_len;
         rs.sd.chunk_field = ctd->d_field;
-        rs.wstat = c->d_wstat;
         rs.slow_count = c->d_slow;
         rs.slow_list = c->d_slow + 1;
         rs.partR = c->d_partR;
@@ -619,7 +618,7 @@ int build(lf_ctx* c, const lf_desc* d) {
 
     // ---- per-source tables.  FREE: the sources of a field are put in order of flux (the layout is ours to choose; a
     // sum over sources does not care), so that a chunk's first source is its faintest and the kernels can pick
-    // cheaper forms of the term per (walker, chunk) - see term_free_upper / term_free_noexp.  NaN fluxes go last.
+    // a cheaper form of the term per (walker, chunk) - see term_free_noexp.  NaN fluxes go last.
     std::vector<int64_t> perm((size_t)N);
     for (int64_t i = 0; i < N; ++i) perm[(size_t)i] = i;
     if (d->variant == LF_FREE)
