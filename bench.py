@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
 # the compiler's assembly (profiles/isa_mix.py -> profiles/r01_isa_mix.txt): FMA = 2, any other fp64
 # VALU instruction = 1.  (The survey's nominal weights - exp/log = 40 flops - would put the same
 # run at ~100 % of peak; DESIGN.md section 4 explains why that figure is not used.)
-FLOPS_PER_TERM = {"free": 54.0, "zevol": 27.0, "fixcomp": 0.0}
+FLOPS_PER_TERM = {"free": 54.0, "zevol": 25.0, "fixcomp": 0.0}
 # free variant: terms of (walker, chunk) pairs whose every source has f / f_tau > 37.5 - the decay factor is exactly
 # 1.0 in binary64 - run term_free_noexp (lf_kernels.h): 30 executed flops, 95 issue cycles (profiles/isa_mix.py: the
 # walker loop holds both forms, 84.1 flops and 269 cycles together).  bench.py counts which pairs of the timed
@@ -41,7 +41,7 @@ SETTLE_STEPS = 20                 # untimed steps after the W warm-up steps, see
 CYCLES_PER_TERM_NOEXP = 95.0
 # issue cycles one wave spends per term (fp64 VALU 4, v_rcp/v_rsq_f64 16, 32-bit VALU 2.5; measured
 # rates in profiles/r01_ubench.txt), for the issue-utilisation figure
-CYCLES_PER_TERM = {"free": 174.0, "zevol": 81.0, "fixcomp": 0.0}
+CYCLES_PER_TERM = {"free": 174.0, "zevol": 74.0, "fixcomp": 0.0}
 # Piece B runs in the same launch.  FREE, per grid node and walker: one Schechter exponential (23 executed flops)
 # and, per field, exp + rsqrt + log + exp: 70 executed flops - from the compiler's assembly of the unrolled walker
 # loop of the grid part (profiles/isa_mix.py: 36 field terms + 8 per-node tails = 2721 flops >= 36 x 70 + 8 x 23).

@@ -562,7 +562,9 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 for (int k = 0; k < ST; ++k) {
                     const double Ls = CMP ? quad_comp(wz.aL, wz.bL, wz.cL, a1[k])
                                           : quad_nofma(wz.aL, wz.bL, wz.cL, a1[k], uu[k]);   // L*(z_i), lumfuncmcmc_z.py:66
-                    const double v = fexp_c(LF_LN10 * (lum[k] - Ls), &tab);             // 10^(lum_i - L*(z_i))
+                    // 10^(lum_i - L*(z_i)): FAST mode has bounded it by 700 from above (lf_prepare: vb), and far below
+                    // fexp_t underflows to 0 by itself - no clamps
+                    const double v = fexp_t(LF_LN10 * (lum[k] - Ls), &tab);
                     acc = fma(-v, wgt[k], acc);             // everything else of the term is in wbase
                 }
             }
