@@ -36,6 +36,7 @@ FLOPS_PER_TERM = {"free": 54.0, "zevol": 25.0, "fixcomp": 0.0}
 # 1.0 in binary64 - run term_free_noexp (lf_kernels.h): 30 executed flops, 95 issue cycles (profiles/isa_mix.py: the
 # walker loop holds both forms, 84.1 flops and 269 cycles together).  bench.py counts which pairs of the timed
 # workload take it (noexp_terms below) so that `achieved` stays the executed count.
+FLOPS_PER_NODE_FIELD_BRIGHT = 17.0   # grid node-fields of (walker, 256-node chunk) pairs that pass the same test: fc itself
 FLOPS_PER_TERM_NOEXP = 30.0
 SETTLE_STEPS = 20                 # untimed steps after the W warm-up steps, see main()
 CYCLES_PER_TERM_NOEXP = 95.0
@@ -134,6 +135,34 @@ def noexp_terms(model, blocks, chunk):
             ok = (aC[:, None] > 0) & (aC[:, None] * (first[None, :] - lF[:, None]) >= 0) & \
                  (10.0 ** (first[None, :] + 17.0) * V[:, None] > 37.5)
             total += float((ok * lens[None, :]).sum())
+    return total / len(blocks)
+
+
+def bright_nodes(model, blocks):
+    """(walker, grid node) pairs per launch that take field_sum_bright: the kernel's test per (walker, chunk of 256
+    nodes) - smallest a4 of the chunk times the walker's smallest V above 37.5 - on the host."""
+    ki = model.kernel_inputs()
+    if ki["variant"] != "free":
+        return 0.0
+    S = ki["size_ln"]
+    logL = np.asarray(ki["logL"]).reshape(S, S)
+    D = np.log10(4.0 * np.pi * (3.086e24 * np.asarray(ki["DL_zarr"])) ** 2)
+    a4 = (10.0 ** (logL - D[None, :] + 17.0)).ravel()
+    nch = -(-a4.size // 256)
+    pad = np.full(nch * 256, np.inf)
+    pad[:a4.size] = a4
+    a4min = pad.reshape(nch, 256).min(axis=1)
+    lens = np.minimum(256, a4.size - 256 * np.arange(nch))
+    a = (2.0 * ki["fcmin"] - 1.0) ** 2
+    ratio = abs(a / (1.0 - a))
+    k0 = 2 if ki["fix_sch_al"] else 3
+    nf = len(ki["field_ind"]) - 1
+    total = 0.0
+    for th in blocks:
+        aC = th[:, -1]
+        V = 1.0 / (th[:, k0:k0 + nf] * 10.0 ** (-np.sqrt(ratio / aC ** 2))[:, None])
+        ok = (aC[:, None] > 0) & (a4min[None, :] * V.min(axis=1)[:, None] > 37.5)
+        total += float((ok * lens[None, :]).sum())
     return total / len(blocks)
 
 
@@ -317,14 +346,17 @@ def main():
         terms = float(args.nsrc) * half                                   # (walker, source) terms per launch
         S, nf = model.size_ln, len(model.Flim)
         grid_flops = float(half) * S * S * (FLOPS_PER_NODE[args.variant] + nf * FLOPS_PER_NODE_FIELD[args.variant])
-        t_noexp = 0.0
+        t_noexp = n_bright = 0.0
         if args.variant == "free" and not args.no_specialise and not args.compress:
             used = sorted({(2 * i) % nblk for i in range(args.steps)} | {(2 * i + 1) % nblk for i in range(args.steps)})
             # sources per chunk = 256 x the geometry's sources per lane (lfmcmc.hip: GEOS, pick_geometry)
             st_of = [8, 2, 8, 8, 4, 4, 6, 4, 2]
             auto_big = -(-args.nsrc // 2048) * -(-half // 16) >= 1024
             st = st_of[args.geometry] if args.geometry >= 0 else (8 if auto_big else 2)
-            t_noexp = noexp_terms(model, [theta_all[j, rank * half:(rank + 1) * half] for j in used], 256 * st)
+            mine = [theta_all[j, rank * half:(rank + 1) * half] for j in used]
+            t_noexp = noexp_terms(model, mine, 256 * st)
+            n_bright = bright_nodes(model, mine)
+            grid_flops -= n_bright * nf * (FLOPS_PER_NODE_FIELD[args.variant] - FLOPS_PER_NODE_FIELD_BRIGHT)
         src_flops = (terms - t_noexp) * FLOPS_PER_TERM[args.variant] + t_noexp * FLOPS_PER_TERM_NOEXP
         alg_flops = src_flops + grid_flops
         alg_bytes = args.nsrc * BYTES_PER_SOURCE[args.variant] + half * 8 * (ndim + 1)
@@ -344,6 +376,7 @@ def main():
                     "terms_per_launch": terms, "flops_per_term_executed": FLOPS_PER_TERM[args.variant],
                     "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
                     "noexp_terms_per_launch": t_noexp, "flops_per_term_noexp": FLOPS_PER_TERM_NOEXP,
+                    "bright_grid_nodes_per_launch": n_bright,
                     "terms_per_s": terms / (avg_ms * 1e-3),
                     # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the term loop needs
                     "valu_issue_frac_at_2p4GHz": ((terms - t_noexp) * CYCLES_PER_TERM[args.variant] + t_noexp * CYCLES_PER_TERM_NOEXP)

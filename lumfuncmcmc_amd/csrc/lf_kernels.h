@@ -632,6 +632,7 @@ struct NodeArrays {
     const double* W;      // FREE: trapz weight * volume_part[k]   else: trapz weight * sum_f integ_part[f]
     const double* a3;     // FREE: logf on the grid                ZEVOL: zarr[k]
     const double* a4;     // FREE: 10^(logf_grid + 17)             ZEVOL: zarr[k]^2
+    const double* a4min;  // FREE: per chunk of 256 nodes, the smallest a4 (for the bright form, field_sum_bright)
     int nnodes;
 };
 
@@ -663,8 +664,34 @@ __device__ __forceinline__ double field_sum(const KConst& kc, const double* __re
     return s;
 }
 
+// The same sum when every node of the workgroup has f / f_tau > 37.5 for every field of this walker (wave-uniform
+// test on the workgroup's faintest node and the walker's smallest V): the decay factor is exactly 1.0 in binary64,
+// so fc^(1/decay) = fc = (1 + num / sqrt(1 + num^2)) / 2 - no exp, no log, no reciprocal.  (The reference's
+// fc ** 1.0 is fc itself: this form is the closer one.)
+template <int NF>
+__device__ __forceinline__ double field_sum_bright(const KConst& kc, const double* __restrict__ r, double alphaC, double a3) {
+    double s = 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const double num = fma(alphaC, a3, r[R_CA + f]);
+        const double w = fma(num, frsqrt(fma(num, num, 1.0)), 1.0);
+        s = fma(0.5 * kc.om0_grid[f], w, s);
+    }
+    return s;
+}
+
 __device__ __forceinline__ double field_sum_nf(const KConst& kc, const double* __restrict__ r, double alphaC, double a3,
-                                               double a4, const MathTables* __restrict__ tab) {
+                                               double a4, const MathTables* __restrict__ tab, bool bright = false) {
+    if (bright) switch (kc.nf) {
+        case 1: return field_sum_bright<1>(kc, r, alphaC, a3);
+        case 2: return field_sum_bright<2>(kc, r, alphaC, a3);
+        case 3: return field_sum_bright<3>(kc, r, alphaC, a3);
+        case 4: return field_sum_bright<4>(kc, r, alphaC, a3);
+        case 5: return field_sum_bright<5>(kc, r, alphaC, a3);
+        case 6: return field_sum_bright<6>(kc, r, alphaC, a3);
+        case 7: return field_sum_bright<7>(kc, r, alphaC, a3);
+        default: return field_sum_bright<8>(kc, r, alphaC, a3);
+    }
     switch (kc.nf) {
         case 1: return field_sum<1>(kc, r, alphaC, a3, a4, tab);
         case 2: return field_sum<2>(kc, r, alphaC, a3, a4, tab);
@@ -675,6 +702,13 @@ __device__ __forceinline__ double field_sum_nf(const KConst& kc, const double* _
         case 7: return field_sum<7>(kc, r, alphaC, a3, a4, tab);
         default: return field_sum<8>(kc, r, alphaC, a3, a4, tab);
     }
+}
+
+// smallest V = 1 / f_tau over the walker's fields (wave-uniform)
+__device__ __forceinline__ double walker_vmin(const KConst& kc, const double* __restrict__ r) {
+    double v = r[R_V];
+    for (int f = 1; f < kc.nf; ++f) v = fmin(v, r[R_V + f]);
+    return v;
 }
 
 template <int VARIANT, int TW>
@@ -690,6 +724,7 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
     const int g = valid ? gi : 0;
     const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0;
     const double a3 = na.a3[g], a4 = na.a4[g];
+    const double a4min = VARIANT == LF_FREE ? na.a4min[c] : 0.0;      // wave-uniform
 #pragma unroll 1
     for (int w = 0; w < nw; ++w) {
         const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
@@ -697,7 +732,8 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
         if (VARIANT == LF_FREE) {
             const double T = fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
             const double alphaC = r[R_ALPHAC];
-            const double s = field_sum_nf(kc, r, alphaC, a3, a4, &tab);
+            const bool bright = kc.specialise && alphaC > 0.0 && a4min * walker_vmin(kc, r) > 37.5;
+            const double s = field_sum_nf(kc, r, alphaC, a3, a4, &tab, bright);
             val = W * T * s;
         } else if (VARIANT == LF_FIXCOMP) {
             val = W * fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
@@ -745,6 +781,8 @@ __device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, co
     const bool valid = b < gc.nb;
     const int bb = valid ? b : 0;
     const double u = gc.U[bb * 16 + n], a4 = gc.A4[bb * 16 + n];
+    // faintest node of the workgroup: bins ascend in flux, the nodes of a bin descend -> last node of the first bin
+    const double a4min_g = gc.A4[min(c * 16, gc.nb - 1) * 16 + 15];
     const int j0 = gc.row0[bb], nr = valid ? gc.nrows[bb] : 0;
     const double* __restrict__ om = gc.omega + gc.off[bb] + n;
     double Lj[GRIDC_MAX_S / BLOCK], PGj[GRIDC_MAX_S / BLOCK];
@@ -774,7 +812,8 @@ __device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, co
 #pragma unroll
             for (int i = 0; i < 8; ++i) R = fma(Tw[min(j0 + k0 + i, gc.S - 1)], o[i], R);
         }
-        const double Fs = field_sum_nf(kc, r, r[R_ALPHAC], u, a4, &tab);
+        const bool bright = kc.specialise && r[R_ALPHAC] > 0.0 && a4min_g * walker_vmin(kc, r) > 37.5;
+        const double Fs = field_sum_nf(kc, r, r[R_ALPHAC], u, a4, &tab, bright);
         red[w * BLOCK + tid] = R * Fs;
     }
     __syncthreads();

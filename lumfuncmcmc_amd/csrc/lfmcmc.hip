@@ -55,7 +55,7 @@ struct lf_ctx {
     std::vector<int64_t> field_ind;
     // device tables
     double *d_lum = nullptr, *d_a1 = nullptr, *d_P = nullptr, *d_U = nullptr;
-    double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr;
+    double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr, *d_a4min = nullptr;
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
@@ -372,7 +372,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         rs.nchD = nchD;
         rs.nresc = nresc;
     }
-    NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->nnodes};
+    NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
     {
         Prof p(c, s, 1);
         int tw = geo.tw, twb = geo.twb;
@@ -566,7 +566,7 @@ void free_ctx(lf_ctx* c) {
         for (int* b : gi_)
             if (b) hipFree(b);
     }
-    double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4,
+    double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min,
                       c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
     for (double* b : bufs)
         if (b) hipFree(b);
@@ -765,6 +765,16 @@ int build(lf_ctx* c, const lf_desc* d) {
     if ((rc = upload(c, &c->d_W, W.data(), nn)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a3, a3.data(), nn)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a4, a4.data(), nn)) != LF_OK) return rc;
+    {
+        // per chunk of 256 nodes the smallest a4 (FREE; NaN-safe: a NaN node keeps the general form)
+        std::vector<double> a4min((nn + lf::BLOCK - 1) / lf::BLOCK, 0.0);
+        for (size_t ch = 0; ch < a4min.size(); ++ch) {
+            double m = HUGE_VAL;
+            for (size_t g = ch * lf::BLOCK; g < std::min(nn, (ch + 1) * lf::BLOCK); ++g) m = std::isnan(a4[g]) ? 0.0 : std::fmin(m, a4[g]);
+            a4min[ch] = d->variant == LF_FREE ? m : 0.0;
+        }
+        if ((rc = upload(c, &c->d_a4min, a4min.data(), a4min.size())) != LF_OK) return rc;
+    }
     LF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int mb = d->max_batch > 0 ? d->max_batch : 1024;
     return ensure_workspace(c, mb, 0, 0);
