@@ -144,8 +144,8 @@ def bright_nodes(model, blocks):
     ki = model.kernel_inputs()
     if ki["variant"] != "free":
         return 0.0
-    S = ki["size_ln"]
-    logL = np.asarray(ki["logL"]).reshape(S, S)
+    logL = np.asarray(ki["logL"])
+    S = logL.shape[0]
     D = np.log10(4.0 * np.pi * (3.086e24 * np.asarray(ki["DL_zarr"])) ** 2)
     a4 = (10.0 ** (logL - D[None, :] + 17.0)).ravel()
     nch = -(-a4.size // 256)
