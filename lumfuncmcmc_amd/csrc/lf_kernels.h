@@ -33,7 +33,10 @@ namespace lf {
 constexpr int BLOCK = 256;   // 4 waves
 constexpr int REC = 32;      // doubles per walker record
 constexpr int MAXF = 8;
-enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2 };
+// SKIP: the walker failed the prior - lnprob is -inf whatever the sums are (the reference returns before lnlike,
+// lumfuncmcmc.py:408): neither its terms nor its grid nodes are evaluated.  SKIPSRC: piece A is already known to be
+// -inf (NEGINF); the grid integral is still computed (lf_lnprob_pieces reports it).
+enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2, MODE_SKIP = 3, MODE_SKIPSRC = 4 };
 enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4 };   // SLOW: some field of the walker takes the careful path
 
 // walker record, FREE / FIXCOMP
@@ -346,7 +349,8 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     neginf = group8_or(neginf);
     // a walker outside the prior, or already known to be -inf, gets lnprob = -inf whatever its sums are:
     // it must not drag its tile onto the careful path (stretch-move proposals leave the box often)
-    if (bad || neginf) m = MODE_FAST;
+    if (bad) m = MODE_SKIP;
+    else if (neginf) m = MODE_SKIPSRC;
     const int slow = group8_or(has_f && m == MODE_SLOW ? 1 : 0);
     if (live && has_f) wmode[(size_t)w * MAXF + f] = m;
     if (live && f == 0) {
@@ -540,7 +544,9 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 // chunk-level facts (the first source of a chunk is its faintest), see term_free_noexp
                 const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
                 const bool noexp = upper && u_first * wf.V > 37.5;
-                if (noexp) {
+                if (mode >= MODE_SKIP) {
+                    // -inf already: nothing to sum
+                } else if (noexp) {
 #pragma unroll
                     for (int k = 0; k < ST; ++k) {
                         const double term = term_free_noexp(wf, a1[k], &tab);
@@ -558,6 +564,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             } else {
                 const WZ wz = nz;
                 nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
+                if (mode < MODE_SKIP)
 #pragma unroll
                 for (int k = 0; k < ST; ++k) {
                     const double Ls = CMP ? quad_comp(wz.aL, wz.bL, wz.cL, a1[k])
@@ -713,7 +720,7 @@ __device__ __forceinline__ double walker_vmin(const KConst& kc, const double* __
 
 template <int VARIANT, int TW>
 __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays& na, const double* __restrict__ wrec,
-                                             int B, int ntiles, int tw, int id, double* __restrict__ partial,
+                                             const int* __restrict__ wmode, int B, int ntiles, int tw, int id, double* __restrict__ partial,
                                              int pstride, const MathTables& tab, double* __restrict__ red) {
     const int tid = threadIdx.x;
     const int c = id / ntiles, tile = id - c * ntiles;
@@ -729,7 +736,9 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
     for (int w = 0; w < nw; ++w) {
         const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
         double val;
-        if (VARIANT == LF_FREE) {
+        if (wmode[(size_t)(w0 + w) * MAXF] == MODE_SKIP) {
+            val = 0.0;                                  // outside the prior: not evaluated
+        } else if (VARIANT == LF_FREE) {
             const double T = fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
             const double alphaC = r[R_ALPHAC];
             const bool bright = kc.specialise && alphaC > 0.0 && a4min * walker_vmin(kc, r) > 37.5;
@@ -770,7 +779,8 @@ struct GridC {
 };
 
 template <int TW>
-__device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, const double* __restrict__ wrec, int B,
+__device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, const double* __restrict__ wrec,
+                                           const int* __restrict__ wmode, int B,
                                            int ntiles, int tw, int id, double* __restrict__ partial, int pstride,
                                            const MathTables& tab, double* __restrict__ red, double* __restrict__ Tw) {
     const int tid = threadIdx.x;
@@ -795,6 +805,10 @@ __device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, co
 #pragma unroll 1
     for (int w = 0; w < nw; ++w) {
         const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+        if (wmode[(size_t)(w0 + w) * MAXF] == MODE_SKIP) {   // outside the prior (block-uniform)
+            red[w * BLOCK + tid] = 0.0;
+            continue;
+        }
         __syncthreads();                                   // the previous walker's T_w has been read
 #pragma unroll
         for (int q = 0; q < GRIDC_MAX_S / BLOCK; ++q) {
@@ -875,8 +889,8 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
     __syncthreads();
     int id = blockIdx.x;
     if (id < nblkB) {
-        if (CMP && VARIANT == LF_FREE && gc.nb > 0) gridc_body<TWB>(kc, gc, wrec, B, ntilesB, twb, id, partB, strideB, tab, red, Tw);
-        else gridsum_body<VARIANT, TWB>(kc, na, wrec, B, ntilesB, twb, id, partB, strideB, tab, red);
+        if (CMP && VARIANT == LF_FREE && gc.nb > 0) gridc_body<TWB>(kc, gc, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red, Tw);
+        else gridsum_body<VARIANT, TWB>(kc, na, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red);
         return;
     }
     id -= nblkB;
