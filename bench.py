@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--walker-tile", type=int, default=0)
     ap.add_argument("--no-taper", action="store_true", help="(default) single pass over the catalogue")
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed loop: no device-sampler / compressed-catalogue legs (profiling runs)")
     ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
@@ -394,7 +395,7 @@ def main():
                           "n_sources": args.nsrc, "walkers_per_gpu": W, "variant": args.variant,
                           "parallelism": "walker-sharded x%d, RCCL all-gather of lnprob" % world},
                "roofline": roofline}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the same workload as real MCMC: the device-resident sampler (theta, accept/reject and the
             # chain stay in HBM; six launches per ensemble step, no host in the loop)
             from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
@@ -407,7 +408,7 @@ def main():
             res["mcmc_device_sampler"] = {"value": W * nst / t2, "unit": "walker-lnprob evals/s", "ms_per_step": t2 / nst * 1e3,
                                           "steps": nst, "acceptance_fraction": float(ds.acceptance_fraction.mean())}
             ds.close()
-        if world == 1 and not args.compress:
+        if world == 1 and not args.compress and not args.no_extras:
             # separately labelled, NOT the headline: the same workload with piece A taken from the compressed
             # catalogue (opt-in "compress" option, csrc/lf_compress.h) - the roofline above is the direct kernel's
             res["compressed_catalogue"] = compressed_leg(ctx, step, fence, out, args.steps, W)
