@@ -352,8 +352,9 @@ def main():
             used = sorted({(2 * i) % nblk for i in range(args.steps)} | {(2 * i + 1) % nblk for i in range(args.steps)})
             # sources per chunk = 256 x the geometry's sources per lane (lfmcmc.hip: GEOS, pick_geometry)
             st_of = [8, 2, 8, 8, 4, 4, 6, 4, 2]
-            auto_big = -(-args.nsrc // 2048) * -(-half // 16) >= 1024
-            st = st_of[args.geometry] if args.geometry >= 0 else (8 if auto_big else 2)
+            chunks = -(-args.nsrc // 2048)                       # pick_geometry of lfmcmc.hip
+            auto_st = 8 if (chunks * -(-half // 16) >= 1024 or chunks * -(-half // 8) >= 1024 or chunks * -(-half // 4) >= 384) else 2
+            st = st_of[args.geometry] if args.geometry >= 0 else auto_st
             mine = [theta_all[j, rank * half:(rank + 1) * half] for j in used]
             t_noexp = noexp_terms(model, mine, 256 * st)
             n_bright = bright_nodes(model, mine)

@@ -185,11 +185,15 @@ constexpr int NGEO = sizeof(GEOS) / sizeof(GEOS[0]);
 
 int pick_geometry(const lf_ctx* c, int B) {
     if (c->opt_geometry >= 0 && c->opt_geometry < NGEO) return (int)c->opt_geometry;
-    // the big tile amortises loads and reductions best; fall back to the small one when it would
-    // leave the 256 CUs with fewer than ~4 workgroups each
-    const int64_t blocks = ((c->N + GEOS[0].st * lf::BLOCK - 1) / (GEOS[0].st * lf::BLOCK)) *
-                           (int64_t)((B + GEOS[0].tw - 1) / GEOS[0].tw);
-    return blocks >= 1024 ? 0 : 1;
+    // The big tile (2048 sources x 16 walkers) amortises loads and reductions best, but the launch wants >= ~1024
+    // workgroups (4 per CU).  Below that keep the 2048-source chunks and shrink the walker tile (16 -> 8 -> 4);
+    // tiny catalogues take the 512-source chunks.  (Measured at B = 128, lf_main in us, geometries 0 / 2 / 3 / 1:
+    // N = 4e5: 98 / 95 / 100 / 122;  2e5: 67 / 60 / 62 / 72;  1e5: 49 / 43 / 42 / 49;  3e4: 39 / 30 / 30 / 30.)
+    const int64_t chunks = (c->N + GEOS[0].st * lf::BLOCK - 1) / (GEOS[0].st * lf::BLOCK);
+    if (chunks * ((B + 15) / 16) >= 1024) return 0;
+    if (chunks * ((B + 7) / 8) >= 1024) return 2;
+    if (chunks * ((B + 3) / 4) >= 384) return 3;
+    return 1;
 }
 
 int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t partR = 0) {
