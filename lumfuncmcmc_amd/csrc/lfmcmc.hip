@@ -513,10 +513,11 @@ int build_compressed(lf_ctx* c) {
     for (int64_t i = 0; i < cc.n; ++i)
         U[(size_t)i] = c->kc.variant == LF_FREE ? std::pow(10.0, out.node[(size_t)i] - LF_FREF) : out.node[(size_t)i] * out.node[(size_t)i];
     int rc;
-    if ((rc = upload(c, &cc.d_lum, lumc.data(), (size_t)cc.n)) != LF_OK) return rc;
-    if ((rc = upload(c, &cc.d_a1, out.node.data(), (size_t)cc.n)) != LF_OK) return rc;
-    if ((rc = upload(c, &cc.d_U, U.data(), (size_t)cc.n)) != LF_OK) return rc;
-    if ((rc = upload(c, &cc.d_W, out.weight.data(), (size_t)cc.n)) != LF_OK) return rc;
+    if ((rc = upload(c, &cc.d_lum, lumc.data(), (size_t)cc.n)) != LF_OK || (rc = upload(c, &cc.d_a1, out.node.data(), (size_t)cc.n)) != LF_OK ||
+        (rc = upload(c, &cc.d_U, U.data(), (size_t)cc.n)) != LF_OK || (rc = upload(c, &cc.d_W, out.weight.data(), (size_t)cc.n)) != LF_OK) {
+        free_cmp(cc);                                        // nothing half-built stays behind
+        return rc;
+    }
     cc.built = true;
     c->cmp = cc;
     // the integration grid, when it is separable (a failure here only leaves the full grid in use)
