@@ -394,7 +394,7 @@ def main():
                                       "(%d in all), 2 half-ensemble calls of %d theta rows per step"
                                       % (args.variant, args.nsrc, W, W * world, half),
                           "n_sources": args.nsrc, "walkers_per_gpu": W, "variant": args.variant,
-                          "parallelism": "walker-sharded x%d, RCCL all-gather of lnprob" % world},
+                          "parallelism": "walker-sharded x%d, %s all-gather of lnprob" % (world, "RCCL" if args.backend == "nccl" else args.backend)},
                "roofline": roofline}
         if world == 1 and not args.no_extras:
             # the same workload as real MCMC: the device-resident sampler (theta, accept/reject and the
