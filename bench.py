@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - walker-lnprob evaluations per second of the HIP path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,10 +9,20 @@ Workload (config.workload): the configuration the metric is quoted on - 10^6 syn
 256 walkers, single-Schechter model with free completeness (LumFuncMCMC.lnprob, the drivers'
 default), fp64.  A step is one ensemble step: two half-ensemble calls of 128 theta rows each
 (what emcee's stretch move issues), i.e. 256 walker-lnprob evaluations over the whole catalogue.
-With N GPUs the walkers are sharded: every rank evaluates its own 256 walkers per step (weak
-scaling: 256 N walkers in all) and each half-step ends with the RCCL all-gather of the
-per-walker lnprob.  Catalogue, grids and theta blocks are resident in HBM before the timed
-region.  One JSON line on stdout (rank 0).
+Catalogue, grids and theta blocks are resident in HBM before the timed region.  One JSON line on
+stdout (rank 0).
+
+Several GPUs (one process per GPU, torch.distributed, backend nccl = RCCL over xGMI):
+  --scaling weak   (default) every rank brings --walkers walkers: N x 256 walkers in all, each half-step is
+                   sharded by walker and ends with the all-gather of the per-walker lnprob.
+  --scaling strong the ensemble is fixed (--walkers in all: 256 for the metric, 1024 for BASELINE config 4,
+                   512 zevol for config 5) and split over the ranks,
+      --shard walkers   by walker: rank r evaluates rows r*B/N .. of every block, all-gather;
+      --shard sources   by source: rank r holds 1/N of every field's sources and of the grid chunks and
+                        evaluates ALL rows, all-reduce(SUM) of B doubles;
+      --shard auto      sources when a rank's slice of a block would be under four 16-walker tiles.
+With N > 1 and weak scaling the line also carries "strong_scaling": the metric's fixed 256-walker
+ensemble timed in the same run, both ways of sharding.
 """
 import argparse
 import json
@@ -108,11 +118,11 @@ def cpu_baseline_allcores(model, theta, nthreads):
             "sample": "%d theta rows of the timed workload over %d OpenMP threads, %.1f s, plain-C scalar loop" % (len(rows), nthreads, dt)}
 
 
-def noexp_terms(model, blocks, chunk):
+def noexp_terms(ki, blocks, chunk):
     """(walker, source) terms per launch that take term_free_noexp, averaged over the theta blocks of the timed
-    workload: the kernel's own test, per (walker, chunk of `chunk` flux-sorted sources of a field), on the host."""
+    workload: the kernel's own test, per (walker, chunk of `chunk` flux-sorted sources of a field), on the host.
+    ki: the kernel inputs of THIS rank's context (its catalogue shard when the sources are sharded)."""
     from lumfuncmcmc_amd.capi import log_flux
-    ki = model.kernel_inputs()
     if ki["variant"] != "free":
         return 0.0
     logf = log_flux(np.asarray(ki["lum"]), np.asarray(ki["DLz"]))
@@ -127,6 +137,8 @@ def noexp_terms(model, blocks, chunk):
         b = -np.sqrt(ratio / aC ** 2)
         for f in range(nf):
             x = np.sort(logf[fi[f]:fi[f + 1]])
+            if x.size == 0:
+                continue
             first = x[::chunk]
             lens = np.diff(np.append(np.arange(0, x.size, chunk), x.size))
             Fl = th[:, k0 + f]
@@ -135,24 +147,26 @@ def noexp_terms(model, blocks, chunk):
             ok = (aC[:, None] > 0) & (aC[:, None] * (first[None, :] - lF[:, None]) >= 0) & \
                  (10.0 ** (first[None, :] + 17.0) * V[:, None] > 37.5)
             total += float((ok * lens[None, :]).sum())
-    return total / len(blocks)
+    return total / max(len(blocks), 1)
 
 
-def bright_nodes(model, blocks):
+def bright_nodes(ki, blocks, part=0, parts=1):
     """(walker, grid node) pairs per launch that take field_sum_bright: the kernel's test per (walker, chunk of 256
-    nodes) - smallest a4 of the chunk times the walker's smallest V above 37.5 - on the host."""
-    ki = model.kernel_inputs()
+    nodes) - smallest a4 of the chunk times the walker's smallest V above 37.5 - on the host.  Also returns the
+    number of grid nodes this rank integrates (its share of the node chunks when the grid is split)."""
+    S = np.asarray(ki["logL"]).shape[0]
+    nch = -(-S * S // 256)
+    lens = np.minimum(256, S * S - 256 * np.arange(nch))
+    mine = (np.arange(nch) % max(parts, 1)) == part
+    nodes = float(lens[mine].sum())
     if ki["variant"] != "free":
-        return 0.0
+        return 0.0, nodes
     logL = np.asarray(ki["logL"])
-    S = logL.shape[0]
     D = np.log10(4.0 * np.pi * (3.086e24 * np.asarray(ki["DL_zarr"])) ** 2)
     a4 = (10.0 ** (logL - D[None, :] + 17.0)).ravel()
-    nch = -(-a4.size // 256)
     pad = np.full(nch * 256, np.inf)
     pad[:a4.size] = a4
     a4min = pad.reshape(nch, 256).min(axis=1)
-    lens = np.minimum(256, a4.size - 256 * np.arange(nch))
     a = (2.0 * ki["fcmin"] - 1.0) ** 2
     ratio = abs(a / (1.0 - a))
     k0 = 2 if ki["fix_sch_al"] else 3
@@ -162,8 +176,33 @@ def bright_nodes(model, blocks):
         aC = th[:, -1]
         V = 1.0 / (th[:, k0:k0 + nf] * 10.0 ** (-np.sqrt(ratio / aC ** 2))[:, None])
         ok = (aC[:, None] > 0) & (a4min[None, :] * V.min(axis=1)[:, None] > 37.5)
-        total += float((ok * lens[None, :]).sum())
-    return total / len(blocks)
+        total += float((ok * (lens * mine)[None, :]).sum())
+    return total / max(len(blocks), 1), nodes
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start the N ranks as children (torch.distributed.run, one
+    process per GPU) BEFORE this process imports torch or touches the GPU, relay rank 0's JSON line, and exit
+    non-zero if any rank failed.  Nothing is exec'ed."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes), see the box's notes
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d, %d JSON lines)\n" % (n, r.returncode, len(lines)))
+        sys.exit(r.returncode or 1)
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    sys.exit(0)
 
 
 def compressed_leg(ctx, step, fence, direct_out, steps, W):
@@ -210,6 +249,157 @@ def compressed_leg(ctx, step, fence, direct_out, steps, W):
     return res
 
 
+def resolve_sharding(args, world):
+    """(scaling, shard) actually run.  Weak scaling is always walker-sharded (more walkers, same catalogue)."""
+    if world == 1 and not args.force_collective:
+        return args.scaling, "walkers"
+    if args.scaling == "weak":
+        return "weak", "walkers"
+    shard = args.shard
+    if shard == "auto":
+        rows_per_rank = -(-(args.walkers // 2) // world)
+        shard = "sources" if rows_per_rank < 64 else "walkers"          # under four 16-walker tiles per call
+    return "strong", shard
+
+
+class Leg(object):
+    """One timed configuration: (total walkers, sharding) -> evaluator over this rank's context."""
+
+    def __init__(self, args, model, dev, local, world, rank, Wtot, shard, nblk=8, seed=1):
+        import torch
+        from lumfuncmcmc_amd import synth
+        from lumfuncmcmc_amd.dist import ShardedLnProb, SourceShardedLnProb, shard_sources, slice_bounds
+        self.args, self.world, self.rank, self.shard, self.Wtot = args, world, rank, shard, Wtot
+        self.half = Wtot // 2
+        self.nblk = nblk
+        ki = model.kernel_inputs()
+        if shard == "sources" and world > 1:
+            self.ev = SourceShardedLnProb(ki, local)
+            self.ctx = self.ev.ctx
+            self.own_ctx = True
+            self.ki = shard_sources(ki, rank, world)
+            self.rows_local, self.row_lo = self.half, 0
+            self.grid_share = (rank, world)
+        else:
+            self.ctx = model.context()
+            self.own_ctx = False
+            self.ev = ShardedLnProb(self.ctx.lnprob_torch, self.ctx.ndim, dev, force_collective=args.force_collective)
+            self.ki = ki
+            bounds, _ = slice_bounds(self.half, world)
+            self.row_lo, hi = bounds[rank]
+            self.rows_local = hi - self.row_lo
+            self.grid_share = (0, 1)
+        ctx = self.ctx
+        if args.geometry >= 0:
+            ctx.set_option("geometry", args.geometry)
+        if args.walker_tile:
+            ctx.set_option("walker_tile", args.walker_tile)
+        if args.taper:
+            ctx.set_option("taper", 1)
+        if args.compress:
+            ctx.set_option("compress", 1)
+        if args.no_specialise:
+            ctx.set_option("specialise", 0)
+        self.ndim = ctx.ndim
+        # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
+        self.theta_all = synth.walkers(args.variant, self.half * nblk, seed=seed).reshape(nblk, self.half, self.ndim)
+        self.blocks = [torch.from_numpy(self.theta_all[i]).to(dev) for i in range(nblk)]
+
+    def step(self, i):
+        a = self.ev.evaluate_tensor(self.blocks[(2 * i) % self.nblk])
+        b = self.ev.evaluate_tensor(self.blocks[(2 * i + 1) % self.nblk])
+        return a, b
+
+    def local_rows(self, used):
+        """theta rows of the blocks `used` that THIS rank's kernels evaluate."""
+        return [self.theta_all[j, self.row_lo:self.row_lo + self.rows_local] for j in used]
+
+    def close(self):
+        if self.own_ctx:
+            self.ev.close()
+
+
+def timed(leg, fence, warmup, steps, profile_level):
+    """W warm-up + settle steps, then `steps` timed steps between two fences.  Returns (seconds, kernel times, last out)."""
+    import gc
+    for i in range(warmup):
+        out = leg.step(i)
+    # settle: a few more untimed steps (clocks, caches, allocator pools) after whatever warm-up was asked for
+    for i in range(SETTLE_STEPS):
+        out = leg.step(i)
+    fence()
+    leg.ctx.kernel_times()                      # clear
+    leg.ctx.set_profiling(profile_level)
+    # no interpreter pauses inside the timed window: with torch imported a full collection walks ~10^6 objects
+    # (40-80 ms, and whether one falls into the window depends on how many objects the flags allocated before)
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    dbg = []
+    for i in range(steps):
+        out = leg.step(i)
+        dbg.append(time.perf_counter() - t0)
+    fence()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("LF_BENCH_DEBUG"):
+        print("debug: host time after each step (ms):", " ".join("%.2f" % (x * 1e3) for x in dbg[:8]), "fence done %.2f" % (dt * 1e3), file=sys.stderr)
+    leg.ctx.set_profiling(0)
+    return dt, leg.ctx.kernel_times(), out
+
+
+def roofline_of(args, leg, model, kt, dt):
+    """fp64-VALU roofline of the dominant kernel (lf_main: per-source sum + grid integral in one launch) on THIS rank:
+    executed flops of its share of the work / its average launch duration (HIP events on the launch stream)."""
+    variant = args.variant
+    k = kt["main"]
+    launches = max(k["launches"], 1)
+    avg_ms = k["ms"] / launches if k["launches"] else dt / args.steps / 2 * 1e3   # no events: the whole call
+    nsrc, rows = leg.ctx.N, leg.rows_local
+    terms = float(nsrc) * rows                                        # (walker, source) terms per launch
+    S, nf = model.size_ln, len(model.Flim)
+    used = sorted({(2 * i) % leg.nblk for i in range(args.steps)} | {(2 * i + 1) % leg.nblk for i in range(args.steps)})
+    mine = leg.local_rows(used)
+    t_noexp = 0.0
+    n_bright, nodes = bright_nodes(leg.ki, mine if (variant == "free" and not args.no_specialise and not args.compress) else [],
+                                   *leg.grid_share)
+    grid_flops = float(rows) * nodes * (FLOPS_PER_NODE[variant] + nf * FLOPS_PER_NODE_FIELD[variant])
+    if variant == "free" and not args.no_specialise and not args.compress and rows > 0:
+        # sources per chunk = 256 x the geometry's sources per lane (lfmcmc.hip: GEOS, pick_geometry)
+        st_of = [8, 2, 8, 8, 4, 4, 6, 4, 2]
+        chunks = -(-nsrc // 2048)                       # pick_geometry of lfmcmc.hip
+        auto_st = 8 if (chunks * -(-rows // 16) >= 1024 or chunks * -(-rows // 8) >= 1024 or chunks * -(-rows // 4) >= 384) else 2
+        st = st_of[args.geometry] if args.geometry >= 0 else auto_st
+        t_noexp = noexp_terms(leg.ki, mine, 256 * st)
+        grid_flops -= n_bright * nf * (FLOPS_PER_NODE_FIELD[variant] - FLOPS_PER_NODE_FIELD_BRIGHT)
+    src_flops = (terms - t_noexp) * FLOPS_PER_TERM[variant] + t_noexp * FLOPS_PER_TERM_NOEXP
+    alg_flops = src_flops + grid_flops
+    alg_bytes = nsrc * BYTES_PER_SOURCE[variant] + rows * 8 * (leg.ndim + 1)
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tf) and leg.world == 1:
+        try:
+            traffic = json.load(open(tf)).get("%s_n%d_b%d" % (variant, nsrc, rows), {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12
+    ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
+    return {"bound": "valu_fp64", "kernel": "lf_main<%s>" % variant, "achieved": ach_tf,
+            "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
+            "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches, "measured_on": "rank 0",
+            "terms_per_launch": terms, "flops_per_term_executed": FLOPS_PER_TERM[variant],
+            "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
+            "noexp_terms_per_launch": t_noexp, "flops_per_term_noexp": FLOPS_PER_TERM_NOEXP,
+            "bright_grid_nodes_per_launch": n_bright,
+            "terms_per_s": terms / (avg_ms * 1e-3),
+            # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the term loop needs
+            "valu_issue_frac_at_2p4GHz": ((terms - t_noexp) * CYCLES_PER_TERM[variant] + t_noexp * CYCLES_PER_TERM_NOEXP)
+                                         / 64.0 / (avg_ms * 1e-3) / (1024 * 2.4e9),
+            "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
+            "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items() if n != "unused"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,14 +407,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--variant", default="free", choices=["free", "fixcomp", "zevol"])
     ap.add_argument("--nsrc", type=int, default=1000000)
-    ap.add_argument("--walkers", type=int, default=256, help="walkers per GPU")
+    ap.add_argument("--walkers", type=int, default=256, help="walkers per GPU (weak scaling) or in all (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --walkers per GPU; strong: --walkers in all, split over the GPUs")
+    ap.add_argument("--shard", default="auto", choices=["walkers", "sources", "auto"],
+                    help="strong scaling: split every block by walker (all-gather) or the catalogue by source (all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--geometry", type=int, default=-1)
     ap.add_argument("--walker-tile", type=int, default=0)
     ap.add_argument("--no-taper", action="store_true", help="(default) single pass over the catalogue")
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
-    ap.add_argument("--no-extras", action="store_true", help="only the timed loop: no device-sampler / compressed-catalogue legs (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed loop: no device-sampler / compressed-catalogue / strong-scaling legs (profiling runs)")
     ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
@@ -234,6 +428,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                  # never returns; this process has not touched torch or the GPU
     # stdout carries exactly ONE line (the JSON): libraries that print there (RCCL's version banner at
     # communicator init does) are sent to stderr from here on
     sys.stdout.flush()
@@ -246,15 +444,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 or args.force_collective:
+    multi = world > 1 or args.force_collective
+    if multi:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
@@ -263,38 +461,15 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from lumfuncmcmc_amd.dist import ShardedLnProb
-    W = args.walkers                       # per GPU
-    half = W // 2
-    model = build_model(args.variant, args.nsrc, W * world, local)
-    ctx = model.context()
-    if args.geometry >= 0:
-        ctx.set_option("geometry", args.geometry)
-    if args.walker_tile:
-        ctx.set_option("walker_tile", args.walker_tile)
-    if args.no_taper:
-        ctx.set_option("taper", 0)
-    if args.taper:
-        ctx.set_option("taper", 1)
-    if args.compress:
-        ctx.set_option("compress", 1)
-    if args.no_specialise:
-        ctx.set_option("specialise", 0)
-    ndim = ctx.ndim
-    from lumfuncmcmc_amd import synth
-    # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
-    nblk = 8
-    theta_all = synth.walkers(args.variant, half * world * nblk, seed=1).reshape(nblk, half * world, ndim)
-    blocks = [torch.from_numpy(theta_all[i]).to(dev) for i in range(nblk)]
-    sharded = ShardedLnProb(ctx.lnprob_torch, ndim, dev, force_collective=args.force_collective)
-
-    def step(i):
-        a = sharded.evaluate_tensor(blocks[(2 * i) % nblk])
-        b = sharded.evaluate_tensor(blocks[(2 * i + 1) % nblk])
-        return a, b
+    scaling, shard = resolve_sharding(args, world)
+    W = args.walkers
+    Wtot = W * world if scaling == "weak" else W
+    if Wtot % 2 or Wtot < 2:
+        raise SystemExit("the ensemble needs an even number of walkers")
+    model = build_model(args.variant, args.nsrc, Wtot, local)
 
     def fence():
-        if world > 1 or args.force_collective:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -303,99 +478,70 @@ def main():
     side = None if args.default_stream else torch.cuda.Stream(device=dev)
     if side is not None:
         torch.cuda.set_stream(side)
-    for i in range(args.warmup):
-        out = step(i)
-    # settle: a few more untimed steps (clocks, caches, allocator pools) after whatever warm-up was asked for
-    for i in range(SETTLE_STEPS):
-        out = step(i)
-    fence()
-    ctx.kernel_times()                      # clear
-    ctx.set_profiling(args.profile_level)
-    # no interpreter pauses inside the timed window: with torch imported a full collection walks ~10^6 objects
-    # (40-80 ms, and whether one falls into the window depends on how many objects the flags allocated before)
-    import gc
-    gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    dbg = []
-    for i in range(args.steps):
-        out = step(i)
-        dbg.append(time.perf_counter() - t0)
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    if os.environ.get("LF_BENCH_DEBUG"):
-        print("debug: host time after each step (ms):", " ".join("%.2f" % (x * 1e3) for x in dbg[:8]), "fence done %.2f" % (dt * 1e3), file=sys.stderr)
-    ctx.set_profiling(0)
-    kt = ctx.kernel_times()
-    if world > 1 or args.force_collective:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), "non-finite lnprob in the timed workload"
 
-    evals = W * world * args.steps
+    def reduce_max(x):
+        if not multi:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    leg = Leg(args, model, dev, local, world, rank, Wtot, shard)
+    ctx, ndim, half = leg.ctx, leg.ndim, leg.half
+    dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level)
+    dt = reduce_max(dt)
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), "non-finite lnprob in the timed workload"
+    step, theta_all, nblk = leg.step, leg.theta_all, leg.nblk
+
+    evals = Wtot * args.steps
     value = evals / dt
+    backend = "RCCL" if args.backend == "nccl" else args.backend
+    if world == 1:
+        par = "1 GPU"
+    elif shard == "sources":
+        par = "source-sharded x%d (1/%d of every field's sources and of the grid chunks per GPU), %s all-reduce of lnprob" % (world, world, backend)
+    else:
+        par = "walker-sharded x%d, %s all-gather of lnprob" % (world, backend)
+    res = None
     if rank == 0:
-        # dominant kernel = lf_main (per-source sum, piece A, plus the grid integral, piece B, in one
-        # launch); one launch = one half-ensemble call on this GPU.  Flops = executed fp64 operations of
-        # the per-source terms plus (free variant) those of the grid integral, ~8 % of the total at N = 1e6; bytes
-        # count the catalogue stream only (the grid arrays are cache-resident)
-        k = kt["main"]
-        launches = max(k["launches"], 1)
-        avg_ms = k["ms"] / launches if k["launches"] else dt / args.steps / 2 * 1e3   # no events: the whole call
-        terms = float(args.nsrc) * half                                   # (walker, source) terms per launch
-        S, nf = model.size_ln, len(model.Flim)
-        grid_flops = float(half) * S * S * (FLOPS_PER_NODE[args.variant] + nf * FLOPS_PER_NODE_FIELD[args.variant])
-        t_noexp = n_bright = 0.0
-        if args.variant == "free" and not args.no_specialise and not args.compress:
-            used = sorted({(2 * i) % nblk for i in range(args.steps)} | {(2 * i + 1) % nblk for i in range(args.steps)})
-            # sources per chunk = 256 x the geometry's sources per lane (lfmcmc.hip: GEOS, pick_geometry)
-            st_of = [8, 2, 8, 8, 4, 4, 6, 4, 2]
-            chunks = -(-args.nsrc // 2048)                       # pick_geometry of lfmcmc.hip
-            auto_st = 8 if (chunks * -(-half // 16) >= 1024 or chunks * -(-half // 8) >= 1024 or chunks * -(-half // 4) >= 384) else 2
-            st = st_of[args.geometry] if args.geometry >= 0 else auto_st
-            mine = [theta_all[j, rank * half:(rank + 1) * half] for j in used]
-            t_noexp = noexp_terms(model, mine, 256 * st)
-            n_bright = bright_nodes(model, mine)
-            grid_flops -= n_bright * nf * (FLOPS_PER_NODE_FIELD[args.variant] - FLOPS_PER_NODE_FIELD_BRIGHT)
-        src_flops = (terms - t_noexp) * FLOPS_PER_TERM[args.variant] + t_noexp * FLOPS_PER_TERM_NOEXP
-        alg_flops = src_flops + grid_flops
-        alg_bytes = args.nsrc * BYTES_PER_SOURCE[args.variant] + half * 8 * (ndim + 1)
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("%s_n%d_b%d" % (args.variant, args.nsrc, half), {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12
-        ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
-        term_waves_per_s = terms / 64.0 / (avg_ms * 1e-3)
-        roofline = {"bound": "valu_fp64", "kernel": "lf_main<%s>" % args.variant, "achieved": ach_tf,
-                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
-                    "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
-                    "terms_per_launch": terms, "flops_per_term_executed": FLOPS_PER_TERM[args.variant],
-                    "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
-                    "noexp_terms_per_launch": t_noexp, "flops_per_term_noexp": FLOPS_PER_TERM_NOEXP,
-                    "bright_grid_nodes_per_launch": n_bright,
-                    "terms_per_s": terms / (avg_ms * 1e-3),
-                    # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the term loop needs
-                    "valu_issue_frac_at_2p4GHz": ((terms - t_noexp) * CYCLES_PER_TERM[args.variant] + t_noexp * CYCLES_PER_TERM_NOEXP)
-                                                 / 64.0 / (avg_ms * 1e-3) / (1024 * 2.4e9),
-                    "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
-                    "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items() if n != "unused"}}
-        res = {"metric": "walker-lnprob evals/sec (10^6 sources, 256 walkers)", "value": value,
+        res = {"metric": "walker-lnprob evals/sec (%s sources, %d walkers%s)" % (
+                   "10^%d" % round(np.log10(args.nsrc)) if 10 ** round(np.log10(args.nsrc)) == args.nsrc else str(args.nsrc),
+                   W, " per GPU" if (scaling == "weak" and world > 1) else ""),
+               "value": value,
                "unit": "walker-lnprob evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "%s completeness, single Schechter: %d synthetic sources, %d walkers per GPU "
-                                      "(%d in all), 2 half-ensemble calls of %d theta rows per step"
-                                      % (args.variant, args.nsrc, W, W * world, half),
-                          "n_sources": args.nsrc, "walkers_per_gpu": W, "variant": args.variant,
-                          "parallelism": "walker-sharded x%d, %s all-gather of lnprob" % (world, "RCCL" if args.backend == "nccl" else args.backend)},
-               "roofline": roofline}
+               "config": {"workload": "%s completeness, single Schechter: %d synthetic sources, %d walkers in all (%s), "
+                                      "2 half-ensemble calls of %d theta rows per step"
+                                      % (args.variant, args.nsrc, Wtot,
+                                         "%d per GPU" % W if scaling == "weak" else "fixed ensemble", half),
+                          "n_sources": args.nsrc, "walkers_per_gpu": Wtot // world if shard == "walkers" else Wtot,
+                          "walkers_total": Wtot, "variant": args.variant, "shard": shard if world > 1 else "none",
+                          "parallelism": par},
+               "roofline": roofline_of(args, leg, model, kt, dt)}
+    if world > 1 and scaling == "weak" and not args.no_extras:
+        # the metric's literal shape - a FIXED ensemble of --walkers walkers - on the same GPUs, in the same run:
+        # sharded by walker (all-gather) and by source (all-reduce)
+        strong = {}
+        for sh in ("walkers", "sources"):
+            try:
+                lg = Leg(args, model, dev, local, world, rank, W, sh, seed=7)
+                nst = max(10, args.steps)
+                saved = args.steps
+                args.steps = nst
+                d2, kt2, o2 = timed(lg, fence, 2, nst, 1)
+                d2 = reduce_max(d2)
+                if rank == 0:
+                    strong[sh] = {"value": W * nst / d2, "unit": "walker-lnprob evals/s", "ms_per_step": d2 / nst * 1e3,
+                                  "walkers_total": W, "rows_per_call_per_gpu": lg.rows_local, "sources_per_gpu": lg.ctx.N,
+                                  "lf_main_ms": kt2["main"]["ms"] / max(kt2["main"]["launches"], 1)}
+                args.steps = saved
+                lg.close()
+            except Exception as e:                 # an extra figure: never at the cost of the bench line
+                strong[sh] = {"error": repr(e)}
+        if rank == 0:
+            res["strong_scaling"] = strong
+    if rank == 0:
         if world == 1 and not args.no_extras:
             # the same workload as real MCMC: the device-resident sampler (theta, accept/reject and the
             # chain stay in HBM; six launches per ensemble step, no host in the loop)
@@ -407,7 +553,9 @@ def main():
             ds.run_mcmc(None, nst)
             t2 = time.perf_counter() - t1
             res["mcmc_device_sampler"] = {"value": W * nst / t2, "unit": "walker-lnprob evals/s", "ms_per_step": t2 / nst * 1e3,
-                                          "steps": nst, "acceptance_fraction": float(ds.acceptance_fraction.mean())}
+                                          "steps": nst, "acceptance_fraction": float(ds.acceptance_fraction.mean()),
+                                          "note": "counts every proposal, as emcee does; proposals outside the prior box are "
+                                                  "-inf without being evaluated (MODE_SKIP)"}
             ds.close()
         if world == 1 and not args.compress and not args.no_extras:
             # separately labelled, NOT the headline: the same workload with piece A taken from the compressed
@@ -417,15 +565,18 @@ def main():
             cb, ref = cpu_baseline(model, args.variant, theta_all[(2 * (args.steps - 1)) % nblk], args.cpu_budget)
             got = out[0].cpu().numpy()[:len(ref)]
             cb["max_rel_diff_gpu_vs_port"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
+            cb["host_cpu_count"] = os.cpu_count()
             res["cpu_baseline"] = cb
             try:
                 # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe the quota)
                 nthr = int(os.environ.get("LF_BENCH_THREADS", min(len(os.sched_getaffinity(0)), 16)))
                 res["cpu_baseline_allcores"] = cpu_baseline_allcores(model, theta_all[0], nthr)
+                res["cpu_baseline_allcores"]["host_cpu_count"] = os.cpu_count()
             except Exception as e:            # the extra figure must never cost the bench line
                 res["cpu_baseline_allcores"] = {"error": str(e)}
         os.write(json_fd, (json.dumps(res) + "\n").encode())
-    if world > 1 or args.force_collective:
+    leg.close()
+    if multi:
         dist.destroy_process_group()
 
 

@@ -140,11 +140,9 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * (same bound; "compress_grid" = 0 keeps the full grid).
  * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
  * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
- * "graph": 1 lets lf_sampler_run replay one captured hipGraph per ensemble step instead of six launches (same
- * kernels, same random numbers, same chain; the step index then lives in device memory); 0 (default) = plain
- * launches - on ROCm 7.0 the replay gains <= 5 % and shows a sporadic ~30 ms stall, see DESIGN.md.
- * One key changes what is computed: "skip_grid" = 1 leaves the expected-count integral (piece B) out
- * of lnprob - for source-sharded ranks other than the first, whose results are summed. */
+ * Two keys change what is computed, for SOURCE-SHARDED ranks whose lnprob values are summed (all-reduce): "skip_grid" = 1
+ * leaves the expected-count integral (piece B) out of lnprob altogether; "grid_share" = part + 65536 * parts makes this
+ * context integrate only the node chunks c with c % parts == part, so that the ranks split piece B as well as piece A. */
 int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
 
 /*

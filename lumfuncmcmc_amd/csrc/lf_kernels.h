@@ -47,6 +47,8 @@ enum { Z_AL = 0, Z_BL = 1, Z_CL = 2, Z_AP = 3, Z_BP = 4, Z_CP = 5, Z_C1 = 6 };
 struct KConst {
     int variant, fix_sch_al, nf, S, ndim;
     int specialise;           // 1: chunk-level term specialisation (term_free_noexp); 0 for A/B runs
+    int grid_part, grid_parts; // source-sharded ranks split piece B too: this context integrates the node chunks c with
+                              // c % grid_parts == grid_part (the others contribute 0); 0 / 1 = the whole grid
     double lnom0_src[MAXF];   // ln(trunc(Omega_0[f]) / sqarcsec)   (int-truncated, lumfuncmcmc.py:285)
     double om0_grid[MAXF];    // Omega_0[f] / sqarcsec              (float, lumfuncmcmc.py:375)
     double fc_ratio;          // |a / (1 - a)|, a = (2 fcmin - 1)^2 (VmaxLumFunc.py:164-165)
@@ -134,11 +136,6 @@ struct StepArgs {
     const double* pos;           // [W][ndim] current positions
     double* prop;                // [halfW][ndim] proposals of the active half
     double* zz;                  // [halfW] stretch factors
-    // replayable form (hipGraph): the step index is read from device memory, step = *d_step - step_off.
-    // The counter is bumped by lf_main of half 0, i.e. after the half-0 prepare has read it (step_off = 0)
-    // and before everything else of the step does (step_off = 1).
-    const unsigned long long* d_step;
-    int step_off;
 };
 struct AcceptArgs {
     int enabled;
@@ -152,7 +149,6 @@ struct AcceptArgs {
     long long* nacc;             // [W]
     double* chain;               // [W][cap][ndim]
     double* chain_lnp;           // [W][cap]
-    const unsigned long long* d_step;   // replayable form: step = t = *d_step - 1 (see StepArgs)
 };
 
 __device__ __forceinline__ void philox4x32(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
@@ -233,8 +229,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     //   y = x_j - (x_j - x_k) z,   z = ((a - 1) u + 1)^2 / a,   j uniform in the other half
     if (sp.enabled) {
         unsigned int rr[4];
-        const unsigned long long step = sp.d_step ? *sp.d_step - (unsigned long long)sp.step_off : sp.step;
-        sampler_draw(step, sp.half, w, 0, sp.seed, rr);
+        sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
         const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
         const int j = (1 - sp.half) * sp.halfW + (int)(((unsigned long long)rr[2] * (unsigned long long)sp.halfW) >> 32);
         const int k = sp.half * sp.halfW + w;
@@ -867,7 +862,6 @@ struct Rescue {
     const int* slow_count;      // how many
     double* partR;
     int nchD, nresc;
-    unsigned long long* bump;   // sampler step counter to advance (graph replay, half 0 only), or NULL
 };
 
 template <int VARIANT, int ST, int TW, int TWB, bool CMP>
@@ -884,10 +878,18 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
         const int first_resc = nblkB + nchA * (tl.ntiles + tl.ntiles_s);
         if ((int)blockIdx.x >= first_resc && *rs.slow_count == 0) return;
     }
-    load_tables(&tab);
-    if (rs.bump && blockIdx.x == 0 && threadIdx.x == 0) *rs.bump += 1ull;   // no reader of the counter in this launch
-    __syncthreads();
     int id = blockIdx.x;
+    if (id < nblkB && kc.grid_parts > 1) {
+        // piece B is split over source-sharded ranks: node chunks that belong to another rank contribute 0 here
+        const int c = id / ntilesB;
+        if (c % kc.grid_parts != kc.grid_part) {
+            const int w0 = (id - c * ntilesB) * twb;
+            if ((int)threadIdx.x < min(twb, B - w0)) partB[(size_t)(w0 + threadIdx.x) * strideB + c] = 0.0;
+            return;
+        }
+    }
+    load_tables(&tab);
+    __syncthreads();
     if (id < nblkB) {
         if (CMP && VARIANT == LF_FREE && gc.nb > 0) gridc_body<TWB>(kc, gc, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red, Tw);
         else gridsum_body<VARIANT, TWB>(kc, na, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red);
@@ -930,9 +932,8 @@ __device__ __forceinline__ void accept_walker(const AcceptArgs& ap, int w, doubl
     const int k = ap.half * ap.halfW + w;
     const double oldlp = ap.lnp[k];
     unsigned int rr[4];
-    const unsigned long long step = ap.d_step ? *ap.d_step - 1ull : ap.step;
-    const long long t = ap.d_step ? (long long)step : ap.t;
-    sampler_draw(step, ap.half, w, 1, ap.seed, rr);
+    const long long t = ap.t;
+    sampler_draw(ap.step, ap.half, w, 1, ap.seed, rr);
     const double lnq = (ap.ndim - 1.0) * log(ap.zz[w]) + newlp - oldlp;
     const bool acc = (log(u53(rr[0], rr[1])) < lnq) && (newlp > -__builtin_huge_val());
     if (lane < ap.ndim) {
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(64) void lf_propose(StepArgs sp) {
     const int w = gt >> 3, f = gt & 7;
     if (w >= sp.halfW) return;
     unsigned int rr[4];
-    sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);       // (the sharded form is never graph-captured)
+    sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
     const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
     const int j = (1 - sp.half) * sp.halfW + (int)(((unsigned long long)rr[2] * (unsigned long long)sp.halfW) >> 32);
     const int k = sp.half * sp.halfW + w;
@@ -965,9 +966,6 @@ __global__ __launch_bounds__(64) void lf_propose(StepArgs sp) {
         sp.prop[(size_t)w * sp.ndim + i] = stretch_point(sp.pos[(size_t)j * sp.ndim + i], sp.pos[(size_t)k * sp.ndim + i], z);
     if (f == 0) sp.zz[w] = z;
 }
-
-// sets the device-side step counter of a sampler before a run of graph replays
-__global__ void lf_setctr(unsigned long long* p, unsigned long long v) { *p = v; }
 
 __global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __restrict__ newlp) {
     const int w = blockIdx.x;

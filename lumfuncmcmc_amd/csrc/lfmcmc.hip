@@ -61,8 +61,6 @@ struct lf_ctx {
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     int64_t opt_taper = 0;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers (second pass over the catalogue)
     int64_t opt_skip_grid = 0;          // 1: leave piece B out (source-sharded ranks other than the first)
-    int64_t opt_graph = 0;              // 1: lf_sampler_run replays a captured hipGraph of one ensemble step (opt-in)
-    uint64_t generation = 0;            // bumped whenever captured launch arguments go stale (workspace, options)
     int64_t opt_compress = 0;           // 1: piece A from the compressed catalogue (FREE, ZEVOL)
     int64_t opt_compress_grid = 1;      // with compress: also the FREE integration grid, when it is separable
     CompressedCat cmp;
@@ -196,16 +194,26 @@ int pick_geometry(const lf_ctx* c, int B) {
     return 1;
 }
 
+// free a device / pinned buffer and clear the pointer: a failed re-allocation below must leave nothing dangling
+template <typename T>
+void release(T*& p) {
+    if (p) hipFree(p);
+    p = nullptr;
+}
+template <typename T>
+void release_host(T*& p) {
+    if (p) hipHostFree(p);
+    p = nullptr;
+}
+
 int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t partR = 0) {
     if (Bpad > c->cap_B) {
         int nb = std::max(Bpad, c->cap_B * 2);
-        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
-        hipFree(c->d_theta); hipFree(c->d_out); hipFree(c->d_outA); hipFree(c->d_outB);
-        hipFree(c->d_wrec); hipFree(c->d_wstat); hipFree(c->d_wmode); hipFree(c->d_wbase);
-        if (c->h_theta) hipHostFree(c->h_theta);
-        if (c->h_out) hipHostFree(c->h_out);
         c->cap_B = 0;
+        release(c->d_theta); release(c->d_out); release(c->d_outA); release(c->d_outB);
+        release(c->d_wrec); release(c->d_wstat); release(c->d_wmode); release(c->d_wbase); release(c->d_slow);
+        release_host(c->h_theta); release_host(c->h_out);
         LF_HIP(c, hipMalloc((void**)&c->d_theta, (size_t)nb * 16 * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_out, (size_t)nb * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_outA, (size_t)nb * sizeof(double)));
@@ -214,8 +222,6 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         LF_HIP(c, hipMalloc((void**)&c->d_wstat, (size_t)nb * sizeof(int)));
         LF_HIP(c, hipMalloc((void**)&c->d_wmode, (size_t)nb * lf::MAXF * sizeof(int)));
         LF_HIP(c, hipMalloc((void**)&c->d_wbase, (size_t)nb * sizeof(double)));
-        if (c->d_slow) hipFree(c->d_slow);
-        c->d_slow = nullptr;
         LF_HIP(c, hipMalloc((void**)&c->d_slow, ((size_t)nb + 1) * sizeof(int)));
         LF_HIP(c, hipMemset(c->d_slow, 0, ((size_t)nb + 1) * sizeof(int)));
         LF_HIP(c, hipHostMalloc((void**)&c->h_theta, (size_t)nb * 16 * sizeof(double), hipHostMallocDefault));
@@ -223,26 +229,23 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         c->cap_B = nb;
     }
     if (partA > c->cap_partA) {
-        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
-        hipFree(c->d_partA);
         c->cap_partA = 0;
+        release(c->d_partA);
         LF_HIP(c, hipMalloc((void**)&c->d_partA, partA * sizeof(double)));
         c->cap_partA = partA;
     }
     if (partR > c->cap_partR) {
-        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
-        hipFree(c->d_partR);
         c->cap_partR = 0;
+        release(c->d_partR);
         LF_HIP(c, hipMalloc((void**)&c->d_partR, partR * sizeof(double)));
         c->cap_partR = partR;
     }
     if (partB > c->cap_partB) {
-        ++c->generation;
         LF_HIP(c, hipDeviceSynchronize());
-        hipFree(c->d_partB);
         c->cap_partB = 0;
+        release(c->d_partB);
         LF_HIP(c, hipMalloc((void**)&c->d_partB, partB * sizeof(double)));
         c->cap_partB = partB;
     }
@@ -312,8 +315,7 @@ void launch_main(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int t
 }
 
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
-            hipStream_t s, const lf::StepArgs* step = nullptr, const lf::AcceptArgs* accept = nullptr,
-            unsigned long long* bump = nullptr) {
+            hipStream_t s, const lf::StepArgs* step = nullptr, const lf::AcceptArgs* accept = nullptr) {
     using namespace lf;
     StepArgs sp{};
     AcceptArgs ap{};
@@ -341,10 +343,6 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     const int nchB = c->opt_skip_grid ? 0 : (cgrid ? (c->gridc.nb + 15) / 16 : (c->nnodes + BLOCK - 1) / BLOCK);
     rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * nchD);
     if (rc != LF_OK) return rc;
-    if (bump && nchB * (int64_t)B + nchA <= 0) {
-        c->err = "internal: a replayable step needs a non-empty lf_main launch";
-        return LF_ERR_ARG;
-    }
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
@@ -358,7 +356,6 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field};
     SrcArrays sa = sd;
     Rescue rs{};
-    rs.bump = bump;
     GridC gc{};
     if (cgrid) {
         const auto& g = c->gridc;
@@ -593,6 +590,8 @@ int build(lf_ctx* c, const lf_desc* d) {
     kc.variant = d->variant;
     kc.fix_sch_al = d->fix_sch_al ? 1 : 0;
     kc.specialise = 1;
+    kc.grid_part = 0;
+    kc.grid_parts = 1;
     kc.nf = nf;
     kc.S = S;
     if (d->variant == LF_FREE) kc.ndim = 2 + (kc.fix_sch_al ? 0 : 1) + nf + 1;
@@ -941,11 +940,6 @@ int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
 
 int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return LF_ERR_ARG;
-    ++c->generation;                    // captured sampler graphs are rebuilt after any option change
-    if (std::strcmp(key, "graph") == 0) {
-        c->opt_graph = value != 0;
-        return LF_OK;
-    }
     if (std::strcmp(key, "geometry") == 0) {
         if (value < -1 || value >= NGEO) {
             c->err = "geometry must be -1 (auto) or an index below " + std::to_string(NGEO);
@@ -973,6 +967,18 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     }
     if (std::strcmp(key, "compress_grid") == 0) {
         c->opt_compress_grid = value != 0;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "grid_share") == 0) {
+        // value = part + parts * 65536: integrate only the node chunks c with c % parts == part (source-sharded ranks,
+        // whose lnprob values are summed); 0 or parts <= 1 = the whole grid
+        const int64_t parts = value >> 16, part = value & 0xffff;
+        if (value < 0 || (parts > 1 && part >= parts)) {
+            c->err = "grid_share must be part + 65536 * parts with part < parts";
+            return LF_ERR_ARG;
+        }
+        c->kc.grid_parts = parts > 1 ? (int)parts : 1;
+        c->kc.grid_part = parts > 1 ? (int)part : 0;
         return LF_OK;
     }
     if (std::strcmp(key, "skip_grid") == 0) {
@@ -1053,12 +1059,6 @@ struct lf_sampler {
     double *d_chain = nullptr, *d_chain_lnp = nullptr;
     long long* d_nacc = nullptr;
     bool started = false;
-    // replayable ensemble step (hipGraph): device-side step counter, the instantiated graph, and the
-    // context generation / stream it was captured for
-    unsigned long long* d_ctr = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
-    uint64_t graph_gen = 0;
 };
 
 lf_sampler* lf_sampler_create(lf_ctx* c, int nwalkers, double a, uint64_t seed, int64_t capacity_steps) {
@@ -1082,8 +1082,7 @@ lf_sampler* lf_sampler_create(lf_ctx* c, int nwalkers, double a, uint64_t seed, 
               hipMalloc((void**)&sm->d_newlp, W * 8) == hipSuccess &&
               hipMalloc((void**)&sm->d_chain, W * cap * nd * 8) == hipSuccess &&
               hipMalloc((void**)&sm->d_chain_lnp, W * cap * 8) == hipSuccess &&
-              hipMalloc((void**)&sm->d_nacc, W * sizeof(long long)) == hipSuccess &&
-              hipMalloc((void**)&sm->d_ctr, sizeof(unsigned long long)) == hipSuccess;
+              hipMalloc((void**)&sm->d_nacc, W * sizeof(long long)) == hipSuccess;
     if (!ok) {
         c->err = "lf_sampler_create: device allocation failed";
         lf_sampler_destroy(sm);
@@ -1099,9 +1098,7 @@ void lf_sampler_destroy(lf_sampler* sm) {
         hipDeviceSynchronize();
     }
     hipFree(sm->d_pos); hipFree(sm->d_lnp); hipFree(sm->d_prop); hipFree(sm->d_zz); hipFree(sm->d_newlp);
-    hipFree(sm->d_chain); hipFree(sm->d_chain_lnp); hipFree(sm->d_nacc); hipFree(sm->d_ctr);
-    if (sm->gexec) hipGraphExecDestroy(sm->gexec);
-    if (sm->graph) hipGraphDestroy(sm->graph);
+    hipFree(sm->d_chain); hipFree(sm->d_chain_lnp); hipFree(sm->d_nacc);
     delete sm;
 }
 
@@ -1139,59 +1136,6 @@ int lf_sampler_run(lf_sampler* sm, int64_t nsteps, void* hip_stream) {
     LF_HIP(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const int halfW = sm->W / 2;
-    // A step is six small launches; at small N (or with the compressed catalogue) it is bound by launch
-    // latency.  Capture ONE step as a hipGraph (step index read from device memory, see StepArgs) and replay it.
-    if (c->opt_graph && c->profiling == 0 && nsteps >= 2 && !(c->N == 0 && c->opt_skip_grid)) {
-        if (!sm->gexec || sm->graph_gen != c->generation) {
-            if (sm->gexec) hipGraphExecDestroy(sm->gexec);
-            if (sm->graph) hipGraphDestroy(sm->graph);
-            sm->gexec = nullptr;
-            sm->graph = nullptr;
-            // a plain step first: sizes the workspace, fills the chunk-table cache and settles the stream
-            // hand-over, none of which may happen inside a capture
-            for (int half = 0; half < 2; ++half) {
-                lf::StepArgs sp{1, half, halfW, sm->ndim, sm->step, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz};
-                lf::AcceptArgs ap{1, half, halfW, sm->ndim, sm->step, sm->seed, (long long)sm->t, (long long)sm->cap,
-                                  sm->d_pos, sm->d_lnp, sm->d_prop, sm->d_zz, sm->d_nacc, sm->d_chain, sm->d_chain_lnp};
-                int rc = enqueue(c, nullptr, halfW, sm->d_newlp, nullptr, nullptr, s, &sp, &ap);
-                if (rc != LF_OK) return rc;
-            }
-            sm->step += 1;
-            sm->t += 1;
-            nsteps -= 1;
-            const uint64_t gen = c->generation;
-            LF_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-            int rc = LF_OK;
-            for (int half = 0; half < 2 && rc == LF_OK; ++half) {
-                lf::StepArgs sp{1, half, halfW, sm->ndim, 0, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz, sm->d_ctr, half};
-                lf::AcceptArgs ap{1, half, halfW, sm->ndim, 0, sm->seed, 0, (long long)sm->cap,
-                                  sm->d_pos, sm->d_lnp, sm->d_prop, sm->d_zz, sm->d_nacc, sm->d_chain, sm->d_chain_lnp, sm->d_ctr};
-                rc = enqueue(c, nullptr, halfW, sm->d_newlp, nullptr, nullptr, s, &sp, &ap, half == 0 ? sm->d_ctr : nullptr);
-            }
-            hipGraph_t g = nullptr;
-            const hipError_t e = hipStreamEndCapture(s, &g);
-            if (rc != LF_OK) {
-                if (g) hipGraphDestroy(g);
-                return rc;
-            }
-            if (e != hipSuccess || c->generation != gen) {
-                if (g) hipGraphDestroy(g);
-                c->err = std::string("lf_sampler_run: graph capture failed: ") + hipGetErrorString(e);
-                return LF_ERR_HIP;
-            }
-            sm->graph = g;
-            LF_HIP(c, hipGraphInstantiate(&sm->gexec, sm->graph, nullptr, nullptr, 0));
-            sm->graph_gen = gen;
-        }
-        if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));   // as enqueue does
-        c->last_stream = s;
-        c->any_enqueued = true;
-        hipLaunchKernelGGL(lf::lf_setctr, dim3(1), dim3(1), 0, s, sm->d_ctr, (unsigned long long)sm->step);
-        for (int64_t it = 0; it < nsteps; ++it) LF_HIP(c, hipGraphLaunch(sm->gexec, s));
-        sm->step += (uint64_t)nsteps;
-        sm->t += nsteps;
-        return LF_OK;
-    }
     for (int64_t it = 0; it < nsteps; ++it) {
         for (int half = 0; half < 2; ++half) {
             lf::StepArgs sp{1, half, halfW, sm->ndim, sm->step, sm->seed, sm->a, sm->d_pos, sm->d_prop, sm->d_zz};

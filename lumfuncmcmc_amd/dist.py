@@ -25,7 +25,7 @@ class ShardedLnProb(object):
     product this is LFContext.lnprob_torch.  Every rank must call with the same block.
     """
 
-    def __init__(self, local_eval, ndim, device, group=None, force_collective=False):
+    def __init__(self, local_eval, ndim, device, group=None, force_collective=False, check_theta=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -33,6 +33,10 @@ class ShardedLnProb(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._buffers = {}
+        self._flip = {}
+        # check_theta: every call first verifies (one small all-reduce) that all ranks passed the SAME block - the
+        # silent failure of this scheme is ranks whose samplers drifted apart (different seeds / starts)
+        self.check_theta = bool(check_theta)
         # a one-rank group normally skips the collective; force_collective keeps it (one-GPU rehearsal of the
         # RCCL path: same calls, same stream ordering, a degenerate gather)
         self._collective = self.world > 1 or (force_collective and dist.is_initialized())
@@ -45,20 +49,38 @@ class ShardedLnProb(object):
         except (TypeError, ValueError):
             self._eval_takes_out = False
 
+    def _assert_same_theta(self, theta):
+        torch, dist = self.torch, self.dist
+        t = theta.detach().to(torch.float64)
+        # min and max over ranks of two position-weighted checksums must coincide
+        wts = torch.arange(1, t.numel() + 1, dtype=torch.float64, device=t.device)
+        flat = torch.nan_to_num(t.reshape(-1), nan=1.0e300, posinf=1.0e301, neginf=-1.0e301)
+        cs = torch.stack([flat.sum(), (flat * wts).sum()])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not bool((lo == hi).all().item()):
+            raise RuntimeError("ShardedLnProb: the ranks passed different theta blocks (rank %d): their samplers have "
+                               "diverged - broadcast the start positions and the sampler seed from rank 0" % self.rank)
+
     def evaluate_tensor(self, theta):
-        """theta: (B, ndim) float64 tensor on self.device -> (B,) tensor on self.device.  The gather
-        buffer is kept per B and the local slice is written straight into it (in-place all-gather:
-        no staging copy, no allocation per call)."""
+        """theta: (B, ndim) float64 tensor on self.device -> (B,) tensor on self.device.  The local slice is
+        written straight into the gather buffer (in-place all-gather: no staging copy, no allocation per call).
+        Two gather buffers per B are used in turn, so the result of a call stays valid while the NEXT call with the
+        same B runs (a sampler holds half 0's lnprob while half 1 is evaluated); it is overwritten by the call after."""
         torch, dist = self.torch, self.dist
         B = theta.shape[0]
         if not self._collective:
             return self.local_eval(theta)
+        if self.check_theta:
+            self._assert_same_theta(theta)
         bounds, per = slice_bounds(B, self.world)
         lo, hi = bounds[self.rank]
-        full = self._buffers.get(B)
+        flip = self._flip[B] = 1 - self._flip.get(B, 1)
+        full = self._buffers.get((B, flip))
         if full is None:
             full = torch.full((per * self.world,), float("-inf"), dtype=torch.float64, device=self.device)
-            self._buffers[B] = full
+            self._buffers[(B, flip)] = full
         mine = full[self.rank * per:(self.rank + 1) * per]
         if not self._inplace:
             mine = self._buffers.setdefault(("in", B), torch.full((per,), float("-inf"), dtype=torch.float64,
@@ -82,9 +104,9 @@ class ShardedLnProb(object):
             dist.all_gather_into_tensor(full, sep, group=self.group)
         if not self._inplace and self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        if per * self.world == B:
-            return full
-        return torch.cat([full[r * per:r * per + (b - a)] for r, (a, b) in enumerate(bounds)])
+        # rank r's rows start at r * per in the block as well as in the gather buffer: the first B entries ARE the
+        # block's lnprob in row order (only the tail is padding)
+        return full[:B]
 
     def __call__(self, theta):
         t = self.torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64)).to(self.device)
@@ -116,7 +138,8 @@ class SourceShardedLnProb(object):
     """The other way to use several GPUs (for batches smaller than a walker tile per GPU):
     every rank holds 1/world of the catalogue and evaluates ALL theta rows on it; the per-source sums
     (and the closed-form walker part, itself a sum over sources) add up, the expected-count integral is
-    computed on rank 0 only, and one all-reduce(SUM) of B doubles gives lnprob on every rank.  A row
+    split by node chunks over the ranks in the same way ("grid_share"), and one all-reduce(SUM) of B doubles
+    gives lnprob on every rank.  A row
     outside the prior or underflowing on any rank is -inf on that rank, hence in the sum.  Only the
     summation order differs from the single-GPU result."""
 
@@ -129,8 +152,9 @@ class SourceShardedLnProb(object):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device("cuda", device)
         self.ctx = LFContext(shard_sources(inp, self.rank, self.world), device=device)
-        if self.rank != 0:
-            self.ctx.set_option("skip_grid", 1)
+        if self.world > 1:
+            # piece B is split like piece A: rank r integrates the node chunks c with c % world == r
+            self.ctx.set_option("grid_share", self.rank + 65536 * self.world)
         self.ndim = self.ctx.ndim
         self._sync = dist.is_initialized() and dist.get_backend(group) != "nccl"
 

@@ -31,6 +31,10 @@ class _Base(object):
     _logger_name = 'lumfuncmcmc'
     device = 0
     compress = False               # True: piece A from the compressed catalogue (csrc/lf_compress.h), opt-in
+    shard = "walkers"              # several ranks (torch.distributed, one process per GPU): "walkers" = every rank holds
+                                   # the catalogue and evaluates a slice of each half-ensemble (all-gather of lnprob);
+                                   # "sources" = every rank holds 1/world of the catalogue and of the grid and evaluates
+                                   # every walker (all-reduce of lnprob) - for ensembles too small to split by walker
 
     # ------------------------------------------------------------------ setup (host, once)
     def _common_init(self, z, flux, flux_e, lum, lum_e):
@@ -141,14 +145,35 @@ class _Base(object):
             inp["integ_part"] = np.array(self.integ_part)
         return inp
 
+    @staticmethod
+    def _dist_state():
+        """(rank, world) of the default torch.distributed group, (0, 1) when there is none."""
+        try:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized():
+                return tdist.get_rank(), tdist.get_world_size()
+        except ImportError:
+            pass
+        return 0, 1
+
     def context(self):
-        """The device context for the current (variant, fixed-parameter) configuration."""
-        key = (self._variant(), bool(self.fix_sch_al), float(self.sch_al) if self.fix_sch_al else None)
+        """The device context for the current (variant, fixed-parameter) configuration.  With shard == "sources"
+        and several ranks it holds this rank's 1/world of the catalogue and of the integration grid: its lnprob is a
+        partial sum that only means something after the all-reduce (fit_model does that)."""
+        rank, world = self._dist_state()
+        by_source = self.shard == "sources" and world > 1
+        key = (self._variant(), bool(self.fix_sch_al), float(self.sch_al) if self.fix_sch_al else None,
+               (rank, world) if by_source else None)
         if self._ctx is None or self._ctx_key != key:
             if self._ctx is not None:
                 self._ctx.close()
-            self._ctx = LFContext(self.kernel_inputs(), device=self.device,
-                                  max_batch=max(8, getattr(self, "nwalkers", 100) // 2))
+            inp = self.kernel_inputs()
+            if by_source:
+                from .dist import shard_sources
+                inp = shard_sources(inp, rank, world)
+            self._ctx = LFContext(inp, device=self.device, max_batch=max(8, getattr(self, "nwalkers", 100) // 2))
+            if by_source:
+                self._ctx.set_option("grid_share", rank + 65536 * world)
             if self.compress:
                 self._ctx.set_option("compress", 1)
             self._ctx_key = key
@@ -189,28 +214,31 @@ class _Base(object):
         pos = self.get_init_walker_values()
         ndim = pos.shape[1]
         start = time.time()
+        # With torch.distributed initialised (one process per GPU) every rank runs the same sampler on the same
+        # ensemble: start positions and the sampler's seed come from rank 0 (each process has its own numpy state).
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        rank, world = self._dist_state()
+        if world > 1:
+            import torch.distributed as tdist
+            box = [pos, seed]
+            tdist.broadcast_object_list(box, src=0)
+            pos, seed = box
+        self.start_pos, self.sampler_seed = np.array(pos), seed       # (start, seed) reproduce the chain
         if self.lnprob_fn is None and getattr(self, "device_sampler", True):
-            # the whole stretch move runs on the device (theta never leaves HBM).  With torch.distributed
-            # initialised (one process per GPU) the walkers of every half-step are sharded over the ranks
-            # and the per-walker lnprob is all-gathered (RCCL) before the accept step; start and seed come
-            # from rank 0 so that every rank carries the same ensemble.
-            seed = int(np.random.randint(0, 2 ** 31 - 1))
-            world = 1
-            try:
-                import torch.distributed as tdist
-                if tdist.is_available() and tdist.is_initialized():
-                    world = tdist.get_world_size()
-                    box = [pos, seed]
-                    tdist.broadcast_object_list(box, src=0)
-                    pos, seed = box
-            except ImportError:
-                pass
+            # the whole stretch move runs on the device (theta never leaves HBM).  With several ranks every half-step
+            # is sharded - by walker (all-gather of lnprob, RCCL) or by source (all-reduce), see `shard` - and
+            # accepted on every rank.
             sampler = DeviceEnsembleSampler(self.context(), self.nwalkers, seed=seed, capacity=self.nsteps)
             if world > 1:
-                sampler.enqueue_sharded(pos, self.nsteps)
+                sampler.enqueue_sharded(pos, self.nsteps, shard=self.shard)
                 sampler.sync()
             else:
                 sampler.run_mcmc(pos, self.nsteps)
+        elif world > 1:
+            # host sampler over a sharded callable (lnprob_fn = dist.ShardedLnProb): the ranks must propose the same
+            # moves, so the random stream is seeded from rank 0's draw, not from each process's global state
+            sampler = EnsembleSampler(self.nwalkers, ndim, getattr(self, self._lnprob_name()), vectorize=True, seed=seed)
+            sampler.run_mcmc(pos, self.nsteps)
         else:
             sampler = EnsembleSampler(self.nwalkers, ndim, getattr(self, self._lnprob_name()), vectorize=True)
             sampler.run_mcmc(pos, self.nsteps, rstate0=np.random.get_state())

@@ -150,48 +150,80 @@ class DeviceEnsembleSampler(object):
             self._started = True
         self.ctx._check(lib.lf_sampler_run(self._h, int(nsteps), None))
 
-    def enqueue_sharded(self, pos, nsteps, group=None, lnprob0=None, force_collective=False):
-        """The same chain with the walkers of every half-step sharded over the ranks of a
-        torch.distributed group (one process per GPU): propose everywhere, evaluate the local slice,
-        all-gather the slice's lnprob (RCCL, in stream order), accept everywhere."""
+    def enqueue_sharded(self, pos, nsteps, group=None, lnprob0=None, force_collective=False, shard="walkers"):
+        """The same chain with every half-step sharded over the ranks of a torch.distributed group (one process
+        per GPU).
+
+        shard="walkers": every rank holds the whole catalogue; propose everywhere, evaluate the local slice of the
+        half, all-gather the slices' lnprob (RCCL, in stream order), accept everywhere.  The chain is bit-identical
+        to the one-GPU chain.
+        shard="sources": this sampler's context holds 1/world of the catalogue (dist.shard_sources) and its share of
+        the grid ("grid_share"); every rank evaluates the WHOLE half on its shard, one all-reduce(SUM) of the half's
+        lnprob, accept everywhere.  Only the summation order differs from the one-GPU chain (1e-13)."""
         import torch
         import torch.distributed as dist
         from .dist import slice_bounds
         lib, ct = self.ctx._lib, self._ct
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
+        dev = torch.device("cuda", self.ctx.device)
+        half = self.nwalkers // 2
+        # force_collective: keep the collective with a one-rank group (one-GPU rehearsal of the RCCL path)
+        collective = world > 1 or (force_collective and dist.is_initialized())
+        nccl = collective and dist.get_backend(group) == "nccl"
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def fence_before():           # gloo (rehearsal) does not order with our launches
+            if collective and not nccl:
+                torch.cuda.current_stream(dev).synchronize()
+
+        def fence_after():            # ... nor its result with the next launch
+            if collective and not nccl:
+                torch.cuda.synchronize(dev)
+
+        by_source = shard == "sources"
+        if shard not in ("walkers", "sources"):
+            raise ValueError("shard must be 'walkers' or 'sources'")
         if pos is not None or not self._started:
             p = np.ascontiguousarray(pos, dtype=np.float64)
             l0 = None if lnprob0 is None else np.ascontiguousarray(lnprob0, dtype=np.float64)
+            if by_source and l0 is None and collective:
+                # the start's lnprob is a sum over the shards too
+                t0 = self.ctx.lnprob_torch(torch.from_numpy(p).to(dev))
+                fence_before()
+                dist.all_reduce(t0, op=dist.ReduceOp.SUM, group=group)
+                fence_after()
+                l0 = np.ascontiguousarray(t0.cpu().numpy())
             self.ctx._check(lib.lf_sampler_start(self._h, self._p(p), self._p(l0)))
             self._started = True
-        half = self.nwalkers // 2
+        if by_source:
+            buf = torch.empty((half,), dtype=torch.float64, device=dev)
+            for _ in range(int(nsteps)):
+                for h in (0, 1):
+                    self.ctx._check(lib.lf_sampler_half_eval(self._h, h, 0, half, ct.c_void_p(buf.data_ptr()), ct.c_void_p(stream)))
+                    if collective:
+                        fence_before()
+                        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+                        fence_after()
+                    self.ctx._check(lib.lf_sampler_half_accept(self._h, h, ct.c_void_p(buf.data_ptr()), ct.c_void_p(stream)))
+            self._keep = buf
+            return
         bounds, per = slice_bounds(half, world)
         lo, hi = bounds[rank]
-        dev = torch.device("cuda", self.ctx.device)
+        # the gather buffer is [world][per]; rank r's rows start at r * per in the half as well, so its first `half`
+        # entries are the half's lnprob in walker order (no re-packing for ragged splits)
         buf = torch.full((per * world,), float("-inf"), dtype=torch.float64, device=dev)
-        # force_collective: keep the all-gather with a one-rank group (one-GPU rehearsal of the RCCL path)
-        collective = world > 1 or (force_collective and dist.is_initialized())
-        inplace = collective and dist.get_backend(group) == "nccl"      # RCCL gathers in place
-        sep = None if (inplace or not collective) else torch.full((per,), float("-inf"), dtype=torch.float64, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        sep = None if (nccl or not collective) else torch.full((per,), float("-inf"), dtype=torch.float64, device=dev)   # RCCL gathers in place
+        mine = buf[rank * per:(rank + 1) * per] if sep is None else sep
         for _ in range(int(nsteps)):
             for h in (0, 1):
-                # slices are padded to `per` rows per rank: the gather buffer is [world][per]
-                mine = buf[rank * per:(rank + 1) * per] if sep is None else sep
                 self.ctx._check(lib.lf_sampler_half_eval(self._h, h, lo, hi, ct.c_void_p(mine.data_ptr() - lo * 8),
                                                          ct.c_void_p(stream)))
                 if collective:
-                    if not inplace:
-                        torch.cuda.current_stream(dev).synchronize()    # gloo (rehearsal) does not order with our launches
+                    fence_before()
                     dist.all_gather_into_tensor(buf, mine, group=group)
-                    if not inplace:
-                        torch.cuda.synchronize(dev)                     # ... nor its result with the next launch
-                    full = buf if per * world == half else torch.cat(
-                        [buf[r * per:r * per + (b - a)] for r, (a, b) in enumerate(bounds)])
-                else:
-                    full = buf[:half]
-                self.ctx._check(lib.lf_sampler_half_accept(self._h, h, ct.c_void_p(full.data_ptr()), ct.c_void_p(stream)))
+                    fence_after()
+                self.ctx._check(lib.lf_sampler_half_accept(self._h, h, ct.c_void_p(buf.data_ptr()), ct.c_void_p(stream)))
         self._keep = buf
 
     def sync(self):

@@ -95,37 +95,6 @@ def test_device_chain_equals_host_replay(variant, n, W):
     ds.close(); ds2.close(); ctx.close()
 
 
-@pytest.mark.parametrize("variant,compress", [("free", 0), ("free", 1), ("zevol", 0)])
-def test_graph_replay_gives_the_same_chain_as_plain_launches(variant, compress):
-    """lf_sampler_run replays one captured hipGraph per ensemble step (step index read from device memory);
-    the chain must be the plain launches' chain bit for bit - across several run calls, a walker-count that
-    is not a tile multiple, an option change (re-capture) and a workspace growth in between."""
-    from lumfuncmcmc_amd.capi import LFContext
-    from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
-    inp = make_inputs(variant, 5000, seed=61)
-    ctx = LFContext(inp, max_batch=8)
-    if compress:
-        ctx.set_option("compress", 1)
-    W, nsteps, seed = 44, 31, 77
-    pos = synth.walkers(variant, W, seed=62)
-    ctx.set_option("graph", 0)
-    plain = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
-    plain.run_mcmc(pos, nsteps)
-    ctx.set_option("graph", 1)
-    g = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
-    g.run_mcmc(pos, 7)
-    g.run_mcmc(None, 1)                                        # a single step takes the plain path
-    ctx.lnprob_batch(synth.walkers(variant, 700, seed=63))     # grows the workspace: the captured pointers are stale
-    g.run_mcmc(None, 9)
-    ctx.set_option("geometry", 1)                              # forces a re-capture; same chunking for 5000 sources
-    ctx.set_option("geometry", -1)
-    g.run_mcmc(None, 14)
-    assert np.array_equal(g.chain, plain.chain)
-    assert np.array_equal(g.lnprobability, plain.lnprobability)
-    assert np.array_equal(g.naccepted, plain.naccepted)
-    plain.close(); g.close(); ctx.close()
-
-
 def test_device_sampler_recovers_a_posterior():
     """End to end on the likelihood itself: sample the fixed-completeness posterior of a catalogue drawn
     from a known Schechter function and check that the chain concentrates near the truth."""
@@ -267,3 +236,70 @@ def test_source_sharded_lnprob_two_ranks_on_one_gpu():
         assert np.array_equal(np.isinf(g0), np.isinf(ref)) and np.isinf(ref).sum() == 2
         fin = np.isfinite(ref)
         np.testing.assert_allclose(g0[fin], ref[fin], rtol=1e-13)   # only the summation order differs
+
+
+def _srcshard_sampler_worker(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from lf_testlib import make_inputs, synth
+    from lumfuncmcmc_amd.capi import LFContext
+    from lumfuncmcmc_amd.dist import shard_sources
+    from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
+    out = {}
+    for variant in ("free", "zevol"):
+        inp = make_inputs(variant, 6007, seed=81)
+        ctx = LFContext(shard_sources(inp, rank, world))
+        ctx.set_option("grid_share", rank + 65536 * world)
+        W, nsteps, seed = 26, 10, 4321
+        pos = synth.walkers(variant, W, seed=82)
+        s = DeviceEnsembleSampler(ctx, W, seed=seed, capacity=nsteps)
+        s.enqueue_sharded(pos, nsteps, shard="sources")
+        s.sync()
+        ref = None
+        if rank == 0:
+            full = LFContext(inp)
+            f = DeviceEnsembleSampler(full, W, seed=seed, capacity=nsteps)
+            f.run_mcmc(pos, nsteps)
+            ref = (f.chain, f.lnprobability, f.naccepted)
+            f.close(); full.close()
+        out[variant] = (s.chain, s.lnprobability, s.naccepted, ref)
+        s.close(); ctx.close()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_source_sharded_sampler_two_ranks_on_one_gpu():
+    """Strong-scaling form for small ensembles: every rank holds half of every field's sources and half of the grid
+    chunks, evaluates the WHOLE half-ensemble on its shard, all-reduce(SUM), accept everywhere.  The accept decisions
+    compare lnprob differences of O(1) against sums whose order changed by ~1e-9 absolute, so over a short chain they
+    agree with the one-GPU chain; positions then agree exactly and lnprob to the summation order."""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_srcshard_sampler_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for variant in ("free", "zevol"):
+        c0, l0, n0, ref = res[0][1][variant]
+        c1, l1, n1, _ = res[1][1][variant]
+        assert np.array_equal(c0, c1) and np.array_equal(l0, l1) and np.array_equal(n0, n1)   # ranks in lock-step
+        assert np.array_equal(n0, ref[2])                      # the same accept decisions as on one GPU
+        assert np.array_equal(c0, ref[0])                      # hence the same positions, bit for bit
+        fin = np.isfinite(ref[1])
+        assert np.array_equal(np.isfinite(l0), fin)
+        np.testing.assert_allclose(l0[fin], ref[1][fin], rtol=1e-13)
