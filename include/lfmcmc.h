@@ -138,12 +138,25 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * With it, FREE contexts whose integration grid is separable (every redshift column has the same luminosity nodes:
  * min_comp_frac = 0) also take piece B over ~40 x 16 shared flux nodes per field instead of the S^2 lattice points
  * (same bound; "compress_grid" = 0 keeps the full grid).
+ * "tables": 1 (default) lets the free variant evaluate the term as the product of two tabulated univariate factors,
+ * g(num) = ln fc and h(y) = 1 / (1 - e^(-10^y)) (piecewise degree-7 polynomials, relative error <= 8e-15 over their
+ * whole domain, lf_tables.h), for (walker, chunk) pairs whose fluxes lie inside the tables and whose lanes of
+ * flux-neighbours are narrower than the tables' margins; 0 = always the general form (A/B runs).
  * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
  * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
  * Two keys change what is computed, for SOURCE-SHARDED ranks whose lnprob values are summed (all-reduce): "skip_grid" = 1
  * leaves the expected-count integral (piece B) out of lnprob altogether; "grid_share" = part + 65536 * parts makes this
  * context integrate only the node chunks c with c % parts == part, so that the ranks split piece B as well as piece A. */
 int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
+
+/* Census of which form of the per-source term / grid node ran since lf_set_option(ctx, "count_forms", 1) (which also
+ * clears it; 0 switches it off again - it costs one atomic per (walker, chunk), so it is off by default).  For
+ * bench.py's executed-flop accounting and the tests.  counts[0..7] = (walker, source) terms evaluated in the general
+ * form, the general form without the exponential, the table-driven form, the table-driven form without the
+ * exponential, the careful (checked) form, terms of walkers that were not evaluated (outside the prior / already
+ * -inf); then (walker, node, field) terms of the grid integral in the general and in the bright form.  FREE variant,
+ * real catalogue (the other variants and the compressed catalogue leave it at 0).  Synchronises the device. */
+int lf_form_counts(lf_ctx *ctx, int64_t counts[8]);
 
 /*
  * Device-resident ensemble sampler: the Goodman & Weare stretch move in its parallel form (two fixed

@@ -43,7 +43,7 @@ EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_ba
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
-           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid")
+           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_form_counts")
 
 _lib = None
 
@@ -90,6 +90,8 @@ def load():
     lib.lf_kernel_times.argtypes = [ctypes.c_void_p, _c_double_p, _c_int64_p]
     lib.lf_set_option.restype = ctypes.c_int
     lib.lf_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]
+    lib.lf_form_counts.restype = ctypes.c_int
+    lib.lf_form_counts.argtypes = [ctypes.c_void_p, _c_int64_p]
     lib.lf_last_error.restype = ctypes.c_char_p
     lib.lf_last_error.argtypes = [ctypes.c_void_p]
     lib.lf_sampler_create.restype = ctypes.c_void_p
@@ -315,6 +317,14 @@ class LFContext(object):
         self._check(self._lib.lf_kernel_times(self._h, ms, n))
         names = ("prepare", "main", "unused", "finalize")
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
+
+    FORM_NAMES = ("general", "general_noexp", "table", "table_noexp", "careful", "skipped", "node_general", "node_bright")
+
+    def form_counts(self):
+        """Census of the term forms since set_option("count_forms", 1): dict name -> count (include/lfmcmc.h)."""
+        n = (ctypes.c_int64 * 8)()
+        self._check(self._lib.lf_form_counts(self._h, n))
+        return {k: int(n[i]) for i, k in enumerate(self.FORM_NAMES)}
 
     def set_option(self, key, value):
         self._check(self._lib.lf_set_option(self._h, key.encode(), int(value)))

@@ -31,16 +31,30 @@
 namespace lf {
 
 constexpr int BLOCK = 256;   // 4 waves
-constexpr int REC = 32;      // doubles per walker record
 constexpr int MAXF = 8;
+constexpr int REC = 8 + 8 * MAXF;   // doubles per walker record: 8 walker scalars, then one block of 8 per field
+constexpr int WM = 8;        // ints per (walker, field) in wmode: {mode, klo, khi, kne, kaC, -, -, -}
 // SKIP: the walker failed the prior - lnprob is -inf whatever the sums are (the reference returns before lnlike,
 // lumfuncmcmc.py:408): neither its terms nor its grid nodes are evaluated.  SKIPSRC: piece A is already known to be
 // -inf (NEGINF); the grid integral is still computed (lf_lnprob_pieces reports it).
 enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2, MODE_SKIP = 3, MODE_SKIPSRC = 4 };
 enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4 };   // SLOW: some field of the walker takes the careful path
 
-// walker record, FREE / FIXCOMP
-enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4, R_LF = 8, R_V = 16, R_CA = 24 };   // R_CA = -alpha_C lF
+// walker record, FREE / FIXCOMP: walker scalars ...
+enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4 };
+// ... and per field f the block r[RF(f, .)]: everything the per-source loop needs for one (walker, field) sits in
+// one 64-B line (one batch of scalar loads)
+enum { F_LF = 0, F_V = 1, F_CA = 2, F_CY = 3 };   // lF = log10(1e-17 Flim); V = 1 / f_tau; cA = -alpha_C lF; cY = -(lF + b)
+__host__ __device__ constexpr int RF(int f, int slot) { return 8 + 8 * f + slot; }
+// integer keys of wmode[(w * MAXF + f) * WM + .], see lf_prepare: the per-(walker, chunk) choice of the term's form is
+// made with scalar integer compares only
+enum { M_MODE = 0, M_KLO = 1, M_KHI = 2, M_KNE = 3, M_KAC = 4 };
+// slots of the census KConst::forms (lf_form_counts)
+enum { FORM_GENERAL = 0, FORM_GENERAL_NOEXP = 1, FORM_TABLE = 2, FORM_TABLE_NOEXP = 3, FORM_CAREFUL = 4, FORM_SKIPPED = 5,
+       FORM_NODE_GENERAL = 6, FORM_NODE_BRIGHT = 7, FORM_COUNT = 8 };
+constexpr double KEY_SCALE = 1048576.0;     // keys of log-flux: (x - x0) * 2^20, 1e-6 dex
+constexpr double KEY_ASCALE = 65536.0;      // keys of alpha_C
+constexpr int KEY_MAX = 2147483000;
 // walker record, ZEVOL
 enum { Z_AL = 0, Z_BL = 1, Z_CL = 2, Z_AP = 3, Z_BP = 4, Z_CP = 5, Z_C1 = 6 };
 
@@ -64,6 +78,11 @@ struct KConst {
     double u_min[MAXF];       // FREE: 10^(min logf + 17)
     double u_max[MAXF];       // FREE: 10^(max logf + 17)
     double z_lo[MAXF], z_hi[MAXF];   // ZEVOL
+    double key_x0;            // FREE: origin of the integer keys of log-flux (the catalogue's smallest logf)
+    int tables;               // FREE: 1 = table-driven form of the term where it applies (default), 0 = general form only
+    // optional census of which form of the term / node ran (bench.py's flop accounting, tests): terms or node-fields
+    // added per (walker, chunk) by one lane; NULL = off (the default: no atomics on the path)
+    unsigned long long* forms;
     // per-field sums for the closed-form part of piece A:
     //   sum_i ln TrueLumFunc_i = n (ln ln10 + ln10 phi*) + c1 (sum(lum_i - 42) - n (L* - 42)) - Q sum P_i
     double slc[MAXF];         // sum (lum_i - 42)
@@ -213,6 +232,16 @@ __device__ __forceinline__ int group8_or(int v) {
     return v;
 }
 
+// conservative integer keys (NaN and out-of-range values give keys that fail every test)
+__device__ __forceinline__ int key_ceil(double v) {
+    if (!(v == v)) return KEY_MAX;
+    return (int)fmin(fmax(ceil(v), 0.0), (double)KEY_MAX);
+}
+__device__ __forceinline__ int key_floor(double v) {
+    if (!(v == v)) return -1;
+    return (int)fmin(fmax(floor(v), -1.0), (double)(KEY_MAX - 1));
+}
+
 // slow: {count, list...} of the walkers flagged STAT_SLOW, for the rescue workgroups of the compressed-catalogue
 // launch (order = arrival order of the atomics; every walker's sums go to its own slots, so the order is immaterial);
 // lf_finalize resets the count.
@@ -310,10 +339,30 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
                 const double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
                 lF = log10(1.0e-17 * Flim);
                 V = 1.0 / (Flim * exp10(b));
+                const double cA = -alphaC * lF, cY = -(lF + b);
                 if (live) {
-                    r[R_LF + f] = lF;
-                    r[R_V + f] = V;
-                    r[R_CA + f] = -alphaC * lF;
+                    r[RF(f, F_LF)] = lF;
+                    r[RF(f, F_V)] = V;
+                    r[RF(f, F_CA)] = cA;
+                    r[RF(f, F_CY)] = cY;
+                    // Where the table-driven form of the term applies, as integer keys of log-flux x (conservatively
+                    // rounded): num = alpha_C x + cA inside the g table, y = x + cY inside the h table, both with
+                    // room for the margins; and from where on h = 1 (f / f_tau > 37.5: decay factor exactly 1.0).
+                    int klo = KEY_MAX, khi = -1, kne = KEY_MAX, kac = KEY_MAX;
+                    if (alphaC > 0.0 && alphaC < 1.0e4) {
+                        const double xlo = fmax((G_NUM_LO + 2.0 * G_MARGIN - cA) / alphaC, H_LO + 2.0 * H_MARGIN - cY);
+                        const double xhi = (G_NUM_HI - 2.0 * G_MARGIN - cA) / alphaC;
+                        const double xne = 1.5740312677277188 - cY;            // log10(37.5)
+                        klo = key_ceil((xlo - kc.key_x0) * KEY_SCALE);
+                        khi = key_floor((xhi - kc.key_x0) * KEY_SCALE);
+                        kne = key_ceil((xne - kc.key_x0) * KEY_SCALE);
+                        kac = key_ceil(alphaC * KEY_ASCALE);
+                    }
+                    int* km = wmode + ((size_t)w * MAXF + f) * WM;
+                    km[M_KLO] = klo;
+                    km[M_KHI] = khi;
+                    km[M_KNE] = kne;
+                    km[M_KAC] = kac;
                 }
             }
             if (kc.nsrc[f] > 0) {
@@ -347,7 +396,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     if (bad) m = MODE_SKIP;
     else if (neginf) m = MODE_SKIPSRC;
     const int slow = group8_or(has_f && m == MODE_SLOW ? 1 : 0);
-    if (live && has_f) wmode[(size_t)w * MAXF + f] = m;
+    if (live && has_f) wmode[((size_t)w * MAXF + f) * WM + M_MODE] = m;
     if (live && f == 0) {
         wbase[w] = base;
         wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0);
@@ -456,6 +505,7 @@ struct SrcArrays {
     const int* chunk_start;
     const int* chunk_len;
     const int* chunk_field;
+    const int* chunk_keys;   // FREE, real catalogue: per chunk {kfirst, klast, kamax, -} (lfmcmc.hip: get_chunks), else NULL
 };
 
 // CMP = the items are the pseudo-sources of the compressed catalogue (lfmcmc.hip: build_compressed): each
@@ -481,7 +531,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
         // piece A is closed-form (wbase): unless one of the tile's walkers needs the per-term underflow
         // checks there is nothing to do here - do not even read the catalogue
         int any_slow = 0;
-        for (int w = 0; w < nw; ++w) any_slow |= (wmode[wi(w) * MAXF + fld] == MODE_SLOW);
+        for (int w = 0; w < nw; ++w) any_slow |= (wmode[(wi(w) * MAXF + fld) * WM] == MODE_SLOW);
         if (!__builtin_amdgcn_readfirstlane(any_slow)) {
             if (tid < nw) partial[wi(tid) * pstride + c] = 0.0;
             return;
@@ -511,13 +561,13 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     // depends on which other walkers share its tile (lnprob is a function of its theta row alone).
     double nxA = 0.0, nxC = 0.0, nxV = 0.0;
     WZ nz{};
-    int nxm = wmode[wi(0) * MAXF + fld];
+    int nxm = wmode[(wi(0) * MAXF + fld) * WM];
     {
         const double* __restrict__ r0 = wrec + wi(0) * REC;
         if (VARIANT == LF_FREE) {
             nxA = r0[R_ALPHAC];
-            nxC = r0[R_CA + fld];
-            nxV = r0[R_V + fld];
+            nxC = r0[RF(fld, F_CA)];
+            nxV = r0[RF(fld, F_V)];
         }
         if (VARIANT == LF_ZEVOL) nz = WZ{r0[Z_AL], r0[Z_BL], r0[Z_CL], r0[Z_AP], r0[Z_BP], r0[Z_CP], r0[Z_C1]};
     }
@@ -525,7 +575,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     for (int w = 0; w < nw; ++w) {
         const int mode = __builtin_amdgcn_readfirstlane(nxm);
         const double* __restrict__ rn = wrec + wi(min(w + 1, nw - 1)) * REC;
-        nxm = wmode[wi(min(w + 1, nw - 1)) * MAXF + fld];
+        nxm = wmode[(wi(min(w + 1, nw - 1)) * MAXF + fld) * WM];
         double acc = 0.0;
         if (mode != MODE_SLOW) {
             if (VARIANT == LF_FREE) {
@@ -534,8 +584,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 wf.cA = nxC;
                 wf.V = nxV;
                 nxA = rn[R_ALPHAC];
-                nxC = rn[R_CA + fld];
-                nxV = rn[R_V + fld];
+                nxC = rn[RF(fld, F_CA)];
+                nxV = rn[RF(fld, F_V)];
                 // chunk-level facts (the first source of a chunk is its faintest), see term_free_noexp
                 const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
                 const bool noexp = upper && u_first * wf.V > 37.5;
@@ -574,8 +624,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             // left to the rescue workgroups (real catalogue); only keep the prefetch chain going
             if (VARIANT == LF_FREE) {
                 nxA = rn[R_ALPHAC];
-                nxC = rn[R_CA + fld];
-                nxV = rn[R_V + fld];
+                nxC = rn[RF(fld, F_CA)];
+                nxV = rn[RF(fld, F_V)];
             }
             if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
         } else {
@@ -585,8 +635,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             const double* __restrict__ r = wrec + wi(w) * REC;
             if (VARIANT == LF_FREE) {
                 nxA = rn[R_ALPHAC];
-                nxC = rn[R_CA + fld];
-                nxV = rn[R_V + fld];
+                nxC = rn[RF(fld, F_CA)];
+                nxV = rn[RF(fld, F_V)];
             }
             if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
 #pragma unroll 1
@@ -598,7 +648,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 double term;
                 if (VARIANT == LF_FREE) {
                     const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
-                                   r[R_LF + fld], r[R_V + fld], kc.lnom0_src[fld], 0.0};
+                                   r[RF(fld, F_LF)], r[RF(fld, F_V)], kc.lnom0_src[fld], 0.0};
                     term = term_free_careful(wf, clum, ca1, cpp, sa.U[g]);
                 } else if (VARIANT == LF_FIXCOMP) {
                     const double v = cpp * r[R_Q];
@@ -621,6 +671,176 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
     }
     __syncthreads();
     reduce_store(red, nw, partial, (size_t)pstride, w0, c, IDX ? widx : nullptr);
+}
+
+// ----------------------------------------------------------------------------------------------
+// piece A, FREE variant, real catalogue: the table-driven form of the term.
+//
+// After the hoisting of the header comment the term of (walker w, source i of field f) is
+//     ln fc(num) / (1 - e^(-f/f_tau)) = g(num_i) h(y_i),   num_i = alpha_C x_i + cA_wf,   y_i = x_i + cY_wf,   x_i = logf_i
+// with g and h UNIVARIATE (lf_tables.h: piecewise degree-7 polynomials, generated and error-checked offline over their
+// whole domain: 8e-15 / 3e-15 relative).  The catalogue is sorted by flux inside a field and a lane holds ST
+// NEIGHBOURS of that order, so all its sources fall on one piece of each table, or just across its end - every
+// piece is fitted G_MARGIN / H_MARGIN beyond its ends for that.  Per (walker, lane): one piece index from the
+// lane's middle source, 2 x 4 ds_read_b128 for the coefficients; per term: two FMAs for the local coordinates and
+// two 7-FMA Horner chains (17 fp64 instructions, 16 of them FMAs) instead of rsqrt + log + exp + reciprocal.
+// Whether a (walker, chunk) pair may take it is decided with scalar integer compares on keys that lf_prepare
+// (walker, field) and get_chunks (chunk) have rounded conservatively: the chunk's fluxes inside both tables with
+// room for the margins, and alpha_C times the widest lane of the chunk within the margin.  Pairs that may not
+// (the sparse bright and faint tails of a field, tiny catalogues, extreme walkers) take the general form.
+// ----------------------------------------------------------------------------------------------
+template <int ST, bool NOEXP, bool MASK>
+__device__ __forceinline__ double table_terms(const double (&x)[ST], int nv, double aC, double cA, double cY,
+                                              const TermTables* __restrict__ tt) {
+    const double xc = x[ST / 2];
+    // g: binade of v = |num| + 1 and its top G_BITS mantissa bits
+    const double numc = fma(aC, xc, cA);
+    const double v = fabs(numc) + 1.0;
+    const int hi = __double2hiint(v) & (int)(0xffffffffu << (20 - G_BITS));
+    const double vlo = __hiloint2double(hi, 0);
+    const bool neg = numc < 0.0;
+    int pg = (hi >> (20 - G_BITS)) - (0x3ff << G_BITS) + (neg ? G_NPOS : 0);
+    pg = min(max(pg, 0), G_N - 1);
+    const double sa = neg ? -aC : aC;                         // t_i = |num_i| + 1 - v_lo = sa x_i + sc
+    const double sc = (neg ? -cA : cA) + (1.0 - vlo);
+    double cg[8], ch[8];
+    {
+        const double2* __restrict__ g2 = reinterpret_cast<const double2*>(tt->g) + pg * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 t = g2[q];
+            cg[2 * q] = t.x;
+            cg[2 * q + 1] = t.y;
+        }
+    }
+    double dy = 0.0;
+    if (!NOEXP) {
+        const double yq = fmin(fmax((xc + cY - H_LO) * (double)H_INV, 0.0), (double)(H_N - 1));
+        const int ph = (int)yq;                                // floor: yq >= 0
+        dy = cY - (H_LO + (double)ph * (1.0 / H_INV));         // t_i = y_i - y_lo = x_i + dy
+        const double2* __restrict__ h2 = reinterpret_cast<const double2*>(tt->h) + ph * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 t = h2[q];
+            ch[2 * q] = t.x;
+            ch[2 * q + 1] = t.y;
+        }
+    }
+    // marker for profiles/isa_mix.py: the basic block that holds it is this form's unrolled term loop
+    if (NOEXP) { if (MASK) asm volatile("; LF_FORM table_noexp_masked"); else asm volatile("; LF_FORM table_noexp"); }
+    else { if (MASK) asm volatile("; LF_FORM table_masked"); else asm volatile("; LF_FORM table"); }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < ST; ++k) {
+        const double pgv = horner7(cg, fma(sa, x[k], sc));
+        if (NOEXP) {
+            acc += MASK ? (k < nv ? pgv : 0.0) : pgv;
+        } else {
+            const double phv = horner7(ch, x[k] + dy);
+            if (MASK) acc += k < nv ? pgv * phv : 0.0;
+            else acc = fma(pgv, phv, acc);
+        }
+    }
+    return acc;
+}
+
+template <int ST, int TW>
+__device__ __forceinline__ void srcsum_free(const KConst& kc, const SrcArrays& sa, const double* __restrict__ wrec,
+                                            const int* __restrict__ wmode, int c, int w0, int nw,
+                                            double* __restrict__ partial, int pstride, const MathTables& tab,
+                                            const TermTables& tt, double* __restrict__ red) {
+    const int tid = threadIdx.x;
+    const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
+    const int kfirst = sa.chunk_keys[4 * c], klast = sa.chunk_keys[4 * c + 1], kamax = sa.chunk_keys[4 * c + 2];
+    // sources are sorted by flux inside a field: the chunk's first is its faintest
+    const double a1_first = sa.a1[s0], u_first = sa.U[s0];
+    const bool full = n == ST * BLOCK;
+    // lane tid holds the ST flux-neighbours s0 + tid ST .. (a 64-B line per lane); slots past the end of the chunk
+    // replay its last source and are masked out of the sums
+    const int nv = min(max(n - tid * ST, 0), ST);
+    double x[ST], uu[ST];
+#pragma unroll
+    for (int k = 0; k < ST; ++k) {
+        const size_t g = (size_t)s0 + min(tid * ST + k, n - 1);
+        x[k] = sa.a1[g];
+        uu[k] = sa.U[g];
+    }
+    struct WP {
+        double aC, cA, cY, V;
+        int mode, klo, khi, kne, kac;
+    };
+    auto fetch = [&](int w) {
+        const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+        const int* __restrict__ km = wmode + ((size_t)(w0 + w) * MAXF + fld) * WM;
+        return WP{r[R_ALPHAC], r[RF(fld, F_CA)], r[RF(fld, F_CY)], r[RF(fld, F_V)], km[M_MODE], km[M_KLO], km[M_KHI], km[M_KNE], km[M_KAC]};
+    };
+    // the NEXT walker's constants are fetched (scalar loads) while the current one computes
+    WP nx = fetch(0);
+#pragma unroll 1
+    for (int w = 0; w < nw; ++w) {
+        const WP cur = nx;
+        nx = fetch(min(w + 1, nw - 1));
+        const int mode = __builtin_amdgcn_readfirstlane(cur.mode);
+        double acc = 0.0;
+        int form = FORM_SKIPPED;
+        if (mode == MODE_SLOW) {
+            // careful path (rare): device-library math, per-term underflow checks, -inf poisoning; items re-read
+            // from memory in a rolled loop so that it adds no register pressure
+            form = FORM_CAREFUL;
+            const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+            const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
+                           r[RF(fld, F_LF)], r[RF(fld, F_V)], kc.lnom0_src[fld], 0.0};
+#pragma unroll 1
+            for (int k = 0; k < ST; ++k) {
+                const int i = k * BLOCK + tid;
+                if (i >= n) break;
+                const size_t g = (size_t)s0 + i;
+                acc += term_free_careful(wf, sa.lum[g], sa.a1[g], sa.P[g], sa.U[g]);
+            }
+        } else if (mode >= MODE_SKIP) {
+            // -inf already (outside the prior, or the brightest source underflows): nothing to sum
+        } else {
+            const bool tab_ok = kc.tables && kfirst >= __builtin_amdgcn_readfirstlane(cur.klo) &&
+                                klast <= __builtin_amdgcn_readfirstlane(cur.khi) &&
+                                __builtin_amdgcn_readfirstlane(cur.kac) <= kamax;
+            if (tab_ok) {
+                const bool ne = kc.specialise && kfirst >= __builtin_amdgcn_readfirstlane(cur.kne);
+                form = ne ? FORM_TABLE_NOEXP : FORM_TABLE;
+                if (full) acc = ne ? table_terms<ST, true, false>(x, nv, cur.aC, cur.cA, cur.cY, &tt)
+                                   : table_terms<ST, false, false>(x, nv, cur.aC, cur.cA, cur.cY, &tt);
+                else acc = ne ? table_terms<ST, true, true>(x, nv, cur.aC, cur.cA, cur.cY, &tt)
+                              : table_terms<ST, false, true>(x, nv, cur.aC, cur.cA, cur.cY, &tt);
+            } else {
+                // general form (lf_math.h: table exp / log, one rsqrt seed), with its own chunk-level shortcut
+                WFree wf{};
+                wf.alphaC = cur.aC;
+                wf.cA = cur.cA;
+                wf.V = cur.V;
+                const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
+                if (upper && u_first * wf.V > 37.5) {
+                    form = FORM_GENERAL_NOEXP;
+                    asm volatile("; LF_FORM general_noexp");
+#pragma unroll
+                    for (int k = 0; k < ST; ++k) {
+                        const double term = term_free_noexp(wf, x[k], &tab);
+                        acc += k < nv ? term : 0.0;
+                    }
+                } else {
+                    form = FORM_GENERAL;
+                    asm volatile("; LF_FORM general");
+#pragma unroll
+                    for (int k = 0; k < ST; ++k) {
+                        const double term = term_free_fast(wf, x[k], uu[k], &tab);
+                        acc += k < nv ? term : 0.0;
+                    }
+                }
+            }
+        }
+        if (kc.forms && tid == 0) atomicAdd(kc.forms + form, (unsigned long long)n);
+        red[w * BLOCK + tid] = acc;
+    }
+    __syncthreads();
+    reduce_store(red, nw, partial, (size_t)pstride, w0, c);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -647,8 +867,8 @@ __device__ __forceinline__ double field_sum(const KConst& kc, const double* __re
     double lF[NF], V[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        lF[f] = r[R_CA + f];
-        V[f] = r[R_V + f];
+        lF[f] = r[RF(f, F_CA)];
+        V[f] = r[RF(f, F_V)];
     }
     double s = 0.0;
 #pragma unroll
@@ -675,7 +895,7 @@ __device__ __forceinline__ double field_sum_bright(const KConst& kc, const doubl
     double s = 0.0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const double num = fma(alphaC, a3, r[R_CA + f]);
+        const double num = fma(alphaC, a3, r[RF(f, F_CA)]);
         const double w = fma(num, frsqrt(fma(num, num, 1.0)), 1.0);
         s = fma(0.5 * kc.om0_grid[f], w, s);
     }
@@ -708,8 +928,8 @@ __device__ __forceinline__ double field_sum_nf(const KConst& kc, const double* _
 
 // smallest V = 1 / f_tau over the walker's fields (wave-uniform)
 __device__ __forceinline__ double walker_vmin(const KConst& kc, const double* __restrict__ r) {
-    double v = r[R_V];
-    for (int f = 1; f < kc.nf; ++f) v = fmin(v, r[R_V + f]);
+    double v = r[RF(0, F_V)];
+    for (int f = 1; f < kc.nf; ++f) v = fmin(v, r[RF(f, F_V)]);
     return v;
 }
 
@@ -731,12 +951,15 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
     for (int w = 0; w < nw; ++w) {
         const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
         double val;
-        if (wmode[(size_t)(w0 + w) * MAXF] == MODE_SKIP) {
+        if (wmode[(size_t)(w0 + w) * MAXF * WM] == MODE_SKIP) {
             val = 0.0;                                  // outside the prior: not evaluated
         } else if (VARIANT == LF_FREE) {
             const double T = fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
             const double alphaC = r[R_ALPHAC];
             const bool bright = kc.specialise && alphaC > 0.0 && a4min * walker_vmin(kc, r) > 37.5;
+            if (kc.forms && tid == 0)
+                atomicAdd(kc.forms + (bright ? FORM_NODE_BRIGHT : FORM_NODE_GENERAL),
+                          (unsigned long long)(min(BLOCK, na.nnodes - c * BLOCK) * kc.nf));
             const double s = field_sum_nf(kc, r, alphaC, a3, a4, &tab, bright);
             val = W * T * s;
         } else if (VARIANT == LF_FIXCOMP) {
@@ -800,7 +1023,7 @@ __device__ __forceinline__ void gridc_body(const KConst& kc, const GridC& gc, co
 #pragma unroll 1
     for (int w = 0; w < nw; ++w) {
         const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
-        if (wmode[(size_t)(w0 + w) * MAXF] == MODE_SKIP) {   // outside the prior (block-uniform)
+        if (wmode[(size_t)(w0 + w) * MAXF * WM] == MODE_SKIP) {   // outside the prior (block-uniform)
             red[w * BLOCK + tid] = 0.0;
             continue;
         }
@@ -870,9 +1093,12 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
                                                  int B, Tiling tl, int nchA, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
                                                  double* __restrict__ partB, int strideB, Rescue rs, GridC gc) {
+    constexpr bool TAB = VARIANT == LF_FREE && !CMP;     // the table-driven per-source form (srcsum_free)
     __shared__ MathTables tab;
+    __shared__ __attribute__((aligned(16))) double ttab[TAB ? sizeof(TermTables) / sizeof(double) : 2];
     __shared__ double red[(TW > TWB ? TW : TWB) * BLOCK];
     __shared__ double Tw[CMP ? GRIDC_MAX_S : 1];
+    TermTables& tt = *reinterpret_cast<TermTables*>(ttab);
     if (CMP) {
         // rescue workgroups have nothing to do unless lf_prepare listed a walker: leave before the table prologue
         const int first_resc = nblkB + nchA * (tl.ntiles + tl.ntiles_s);
@@ -889,6 +1115,7 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
         }
     }
     load_tables(&tab);
+    if (TAB && id >= nblkB) load_term_tables(&tt);
     __syncthreads();
     if (id < nblkB) {
         if (CMP && VARIANT == LF_FREE && gc.nb > 0) gridc_body<TWB>(kc, gc, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red, Tw);
@@ -922,7 +1149,8 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
         w0 = tl.B1 + (wg - c * tl.ntiles_s) * tl.tws;
         nw = min(tl.tws, B - w0);
     }
-    srcsum_body<VARIANT, ST, TW, CMP>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
+    if constexpr (TAB) srcsum_free<ST, TW>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, tt, red);
+    else srcsum_body<VARIANT, ST, TW, CMP>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
 }
 
 // accept / reject walker k = half*halfW + w with the new lnprob `newlp`, and record it in the chain

@@ -8,6 +8,8 @@
 //   flog_half  table-driven: 256 x {1/c, log c} in LDS, degree-5 log1p on |r| < 2^-9
 //   frsqrt     v_rsq_f64 seed (2^-24 measured on gfx950) + one cubic step
 //   frcp       v_rcp_f64 seed (2^-24) + one cubic Newton step
+//   TermTables piecewise degree-7 polynomials of the two univariate factors of the free-completeness term,
+//              g(num) = ln fc and h(y) = 1 / (1 - e^(-10^y)) (lf_tables.h, gen_tables.py): the per-source fast path
 // The "careful" path (rare walkers that may underflow, see lf_kernels.h) uses the ROCm device
 // library (ocml) versions; tests compare both against the oracle.
 #pragma once
@@ -120,6 +122,31 @@ __device__ __forceinline__ double frcp(double d) {
     const double y0 = __builtin_amdgcn_rcp(d);
     const double e = fma(-d, y0, 1.0);
     return fma(y0, fma(e, e, e), y0);
+}
+
+// LDS image of G_TABLE / H_TABLE (lf_tables.h): 8 coefficients (64 B) per piece
+struct TermTables {
+    double g[G_N * 8];
+    double h[H_N * 8];
+};
+__device__ __forceinline__ void load_term_tables(TermTables* tt) {
+    double2* g2 = reinterpret_cast<double2*>(tt->g);
+    double2* h2 = reinterpret_cast<double2*>(tt->h);
+    const double2* G2 = reinterpret_cast<const double2*>(G_TABLE);
+    const double2* H2 = reinterpret_cast<const double2*>(H_TABLE);
+    for (int i = threadIdx.x; i < G_N * 4; i += blockDim.x) g2[i] = G2[i];
+    for (int i = threadIdx.x; i < H_N * 4; i += blockDim.x) h2[i] = H2[i];
+}
+
+// degree-7 Horner from 8 coefficients held in registers
+__device__ __forceinline__ double horner7(const double (&c)[8], double t) {
+    double p = fma(c[7], t, c[6]);
+    p = fma(p, t, c[5]);
+    p = fma(p, t, c[4]);
+    p = fma(p, t, c[3]);
+    p = fma(p, t, c[2]);
+    p = fma(p, t, c[1]);
+    return fma(p, t, c[0]);
 }
 
 // copy the tables to LDS (call with all threads, then __syncthreads())

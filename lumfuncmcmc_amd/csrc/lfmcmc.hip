@@ -27,6 +27,7 @@ struct ChunkTable {
     int* d_start = nullptr;
     int* d_len = nullptr;
     int* d_field = nullptr;
+    int* d_keys = nullptr;     // FREE, real catalogue: {kfirst, klast, kamax, 0} per chunk (lf_kernels.h: srcsum_free)
 };
 
 struct EventPair {
@@ -53,6 +54,8 @@ struct lf_ctx {
     int64_t N = 0;
     int nnodes = 0;
     std::vector<int64_t> field_ind;
+    std::vector<double> h_x;            // FREE: host copy of the flux-sorted logf (chunk keys are derived from it)
+    unsigned long long* d_forms = nullptr;   // census of the term forms (option "count_forms"), FORM_COUNT slots
     // device tables
     double *d_lum = nullptr, *d_a1 = nullptr, *d_P = nullptr, *d_U = nullptr;
     double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr, *d_a4min = nullptr;
@@ -115,8 +118,9 @@ int upload(lf_ctx* c, T** dst, const T* src, size_t n) {
     return LF_OK;
 }
 
+// hx: the flux-sorted logf of the REAL catalogue (FREE), or NULL (no keys: the chunks never take the table form)
 int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<int64_t>& field_ind, int ch,
-               ChunkTable** out) {
+               ChunkTable** out, const double* hx = nullptr) {
     auto it = tables.find(ch);
     if (it != tables.end()) {
         *out = &it->second;
@@ -162,12 +166,38 @@ int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<i
             fl.swap(fl2);
         }
     }
+    // Keys for the table-driven form of the FREE term (lf_kernels.h: srcsum_free), rounded so that a key test that
+    // passes implies the real-valued condition: kfirst = floor, klast = ceil of (x - x0) 2^20 for the chunk's
+    // faintest / brightest source; kamax = the largest alpha_C (x 2^16, floor) for which alpha_C times the widest
+    // lane of the chunk (a lane = ch / 256 neighbours in flux) stays within the g table's margin - 0 when that
+    // width already exceeds the h table's margin.  A chunk with a non-finite flux gets keys that fail every test.
+    std::vector<int> keys(4 * st.size(), 0);
+    for (size_t i = 0; i < st.size(); ++i) {
+        keys[4 * i] = -1;
+        keys[4 * i + 1] = lf::KEY_MAX;
+        if (!hx) continue;
+        const int64_t s = st[i], n = ln[i];
+        const int lane_w = ch / lf::BLOCK;
+        double spread = 0.0;
+        bool finite = true;
+        for (int64_t j = 0; j < n; ++j) finite = finite && std::isfinite(hx[s + j]);
+        if (!finite) continue;
+        for (int64_t j = 0; j < n; j += lane_w) spread = std::fmax(spread, hx[s + std::min<int64_t>(j + lane_w, n) - 1] - hx[s + j]);
+        const double k0 = std::floor((hx[s] - c->kc.key_x0) * lf::KEY_SCALE), k1 = std::ceil((hx[s + n - 1] - c->kc.key_x0) * lf::KEY_SCALE);
+        if (!(k0 >= 0.0 && k1 < (double)lf::KEY_MAX)) continue;
+        double amax = spread > 0.0 ? lf::G_MARGIN / spread : 3.0e4;
+        if (spread > lf::H_MARGIN) amax = 0.0;
+        keys[4 * i] = (int)k0;
+        keys[4 * i + 1] = (int)k1;
+        keys[4 * i + 2] = (int)std::floor(std::fmin(amax, 3.0e4) * lf::KEY_ASCALE);
+    }
     ChunkTable t;
     t.n = (int)st.size();
     int rc;
     if ((rc = upload(c, &t.d_start, st.data(), st.size())) != LF_OK) return rc;
     if ((rc = upload(c, &t.d_len, ln.data(), ln.size())) != LF_OK) return rc;
     if ((rc = upload(c, &t.d_field, fl.data(), fl.size())) != LF_OK) return rc;
+    if ((rc = upload(c, &t.d_keys, keys.data(), keys.size())) != LF_OK) return rc;
     tables[ch] = t;
     *out = &tables[ch];
     return LF_OK;
@@ -220,7 +250,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         LF_HIP(c, hipMalloc((void**)&c->d_outB, (size_t)nb * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_wrec, (size_t)nb * lf::REC * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_wstat, (size_t)nb * sizeof(int)));
-        LF_HIP(c, hipMalloc((void**)&c->d_wmode, (size_t)nb * lf::MAXF * sizeof(int)));
+        LF_HIP(c, hipMalloc((void**)&c->d_wmode, (size_t)nb * lf::MAXF * lf::WM * sizeof(int)));
         LF_HIP(c, hipMalloc((void**)&c->d_wbase, (size_t)nb * sizeof(double)));
         LF_HIP(c, hipMalloc((void**)&c->d_slow, ((size_t)nb + 1) * sizeof(int)));
         LF_HIP(c, hipMemset(c->d_slow, 0, ((size_t)nb + 1) * sizeof(int)));
@@ -331,10 +361,11 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     }
     const Geo geo = GEOS[gi];
     ChunkTable *ct = nullptr, *ctd = nullptr;
+    const double* hx = c->h_x.empty() ? nullptr : c->h_x.data();
     int rc = cmp ? get_chunks(c, c->cmp.chunks, c->cmp.field_ind, geo.st * BLOCK, &ct)
-                 : get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ct);
+                 : get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ct, hx);
     if (rc != LF_OK) return rc;
-    if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd)) != LF_OK) return rc;
+    if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd, hx)) != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchD = cmp ? ctd->n : 0;
     // rescue workgroups leave at once unless a walker was flagged; still, each costs a dispatch slot: scale with B
@@ -353,7 +384,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
                            c->d_wstat, c->d_wmode, c->d_wbase, cmp ? c->d_slow : nullptr);
     }
-    const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field};
+    const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys};
     SrcArrays sa = sd;
     Rescue rs{};
     GridC gc{};
@@ -362,11 +393,12 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         gc = GridC{g.d_U, g.d_A4, g.d_row0, g.d_nrows, g.d_off, g.d_omega, g.d_L, g.d_PGL, g.nb, c->kc.S};
     }
     if (cmp) {
-        sa = SrcArrays{c->cmp.d_lum, c->cmp.d_a1, c->cmp.d_lum, c->cmp.d_U, c->cmp.d_W, ct->d_start, ct->d_len, ct->d_field};
+        sa = SrcArrays{c->cmp.d_lum, c->cmp.d_a1, c->cmp.d_lum, c->cmp.d_U, c->cmp.d_W, ct->d_start, ct->d_len, ct->d_field, ct->d_keys};
         rs.sd = sd;
         rs.sd.chunk_start = ctd->d_start;
         rs.sd.chunk_len = ctd->d_len;
         rs.sd.chunk_field = ctd->d_field;
+        rs.sd.chunk_keys = ctd->d_keys;
         rs.slow_count = c->d_slow;
         rs.slow_list = c->d_slow + 1;
         rs.partR = c->d_partR;
@@ -435,6 +467,7 @@ void free_cmp(CompressedCat& cc) {
         hipFree(kv.second.d_start);
         hipFree(kv.second.d_len);
         hipFree(kv.second.d_field);
+        hipFree(kv.second.d_keys);
     }
     cc.chunks.clear();
     double* bufs[] = {cc.d_lum, cc.d_a1, cc.d_U, cc.d_W};
@@ -556,6 +589,7 @@ void free_ctx(lf_ctx* c) {
         hipFree(kv.second.d_start);
         hipFree(kv.second.d_len);
         hipFree(kv.second.d_field);
+        hipFree(kv.second.d_keys);
     }
     free_cmp(c->cmp);
     if (c->d_partR) hipFree(c->d_partR);
@@ -576,6 +610,7 @@ void free_ctx(lf_ctx* c) {
     if (c->d_wmode) hipFree(c->d_wmode);
     if (c->d_wbase) hipFree(c->d_wbase);
     if (c->d_slow) hipFree(c->d_slow);
+    if (c->d_forms) hipFree(c->d_forms);
     if (c->h_theta) hipHostFree(c->h_theta);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -592,6 +627,9 @@ int build(lf_ctx* c, const lf_desc* d) {
     kc.specialise = 1;
     kc.grid_part = 0;
     kc.grid_parts = 1;
+    kc.tables = 1;
+    kc.key_x0 = 0.0;
+    kc.forms = nullptr;
     kc.nf = nf;
     kc.S = S;
     if (d->variant == LF_FREE) kc.ndim = 2 + (kc.fix_sch_al ? 0 : 1) + nf + 1;
@@ -699,6 +737,14 @@ int build(lf_ctx* c, const lf_desc* d) {
         kc.som[f] = (double)som;
         kc.sz[f] = (double)sz;
         kc.sz2[f] = (double)sz2;
+    }
+    if (d->variant == LF_FREE) {
+        // origin of the integer keys of log-flux, and the host copy of the sorted fluxes the chunk keys come from
+        double x0 = HUGE_VAL;
+        for (int64_t i = 0; i < N; ++i)
+            if (std::isfinite(a1[(size_t)i])) x0 = std::fmin(x0, a1[(size_t)i]);
+        kc.key_x0 = std::isfinite(x0) ? x0 : 0.0;
+        c->h_x = a1;
     }
     int rc;
     if ((rc = upload(c, &c->d_lum, lumv.data(), (size_t)N)) != LF_OK) return rc;
@@ -938,6 +984,18 @@ int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
     return LF_OK;
 }
 
+int lf_form_counts(lf_ctx* c, int64_t counts[8]) {
+    if (!c || !counts) return LF_ERR_ARG;
+    for (int i = 0; i < lf::FORM_COUNT; ++i) counts[i] = 0;
+    if (!c->d_forms) return LF_OK;
+    LF_HIP(c, hipSetDevice(c->device));
+    LF_HIP(c, hipDeviceSynchronize());
+    unsigned long long h[lf::FORM_COUNT];
+    LF_HIP(c, hipMemcpy(h, c->d_forms, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < lf::FORM_COUNT; ++i) counts[i] = (int64_t)h[i];
+    return LF_OK;
+}
+
 int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return LF_ERR_ARG;
     if (std::strcmp(key, "geometry") == 0) {
@@ -959,6 +1017,20 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             if (rc != LF_OK) return rc;
         }
         c->opt_compress = value != 0;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "count_forms") == 0) {
+        hipSetDevice(c->device);
+        if (value != 0 && !c->d_forms) LF_HIP(c, hipMalloc((void**)&c->d_forms, lf::FORM_COUNT * sizeof(unsigned long long)));
+        if (c->d_forms) {
+            LF_HIP(c, hipDeviceSynchronize());
+            LF_HIP(c, hipMemset(c->d_forms, 0, lf::FORM_COUNT * sizeof(unsigned long long)));
+        }
+        c->kc.forms = value != 0 ? c->d_forms : nullptr;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "tables") == 0) {
+        c->kc.tables = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "specialise") == 0) {

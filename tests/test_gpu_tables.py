@@ -1,0 +1,85 @@
+"""The table-driven form of the free-completeness term (lf_kernels.h: srcsum_free / table_terms) against the general
+form of the same kernel and against the oracle, on catalogues dense enough for it to apply; the census of forms
+(lf_form_counts) tells which form actually ran.  Reference: lumfuncmcmc.py:370 (piece A), VmaxLumFunc.py:118-127."""
+import numpy as np
+import pytest
+
+from lf_testlib import O, compare_rows, make_inputs, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(n, seed, wide=False):
+    th = synth.walkers("free", n, seed=seed)
+    if wide:                                       # the whole prior box of the completeness parameters
+        rng = np.random.default_rng(seed + 1)
+        th[:, 3:8] = rng.uniform(1.0, 6.0, (n, 5))
+        th[:, 8] = rng.uniform(1.0, 7.0, n)
+    return th
+
+
+@pytest.mark.parametrize("n,wide", [(400003, False), (400003, True), (1000000, False), (60011, False)])
+def test_table_form_equals_general_form(n, wide):
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", n, seed=91)
+    ctx = LFContext(inp)
+    th = _rows(96, 92, wide)
+    th[5, 0] = 40.2                                # underflow zone: -inf
+    th[6, 1] = 6.0                                 # outside the prior
+    ctx.set_option("count_forms", 1)
+    a1, b1 = ctx.lnprob_pieces(th)
+    lp1 = ctx.lnprob_batch(th)
+    fc = ctx.form_counts()
+    ctx.set_option("count_forms", 0)
+    ctx.set_option("tables", 0)
+    a0, b0 = ctx.lnprob_pieces(th)
+    lp0 = ctx.lnprob_batch(th)
+    ctx.close()
+    tab = fc["table"] + fc["table_noexp"]
+    gen = fc["general"] + fc["general_noexp"]
+    assert fc["careful"] == 0
+    if n >= 400000 and not wide:
+        assert tab > 0.9 * (tab + gen), fc          # the bulk of a dense catalogue takes the table form
+    if n < 100000:
+        assert tab > 0, fc
+    assert np.array_equal(np.isnan(a1), np.isnan(a0)) and np.array_equal(np.isinf(lp1), np.isinf(lp0))
+    assert np.isinf(lp1[5]) and np.isinf(lp1[6])
+    fin = np.isfinite(lp0)
+    # piece A = closed-form Schechter part + the completeness sum: the two forms of the latter agree to the tables'
+    # error (8e-15 per term, far less in the sum) plus rounding
+    np.testing.assert_allclose(a1[fin], a0[fin], rtol=5e-14)
+    np.testing.assert_array_equal(b1[fin], b0[fin])     # the grid integral does not depend on the option
+    np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=5e-14)
+
+
+def test_table_form_against_the_oracle():
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", 300007, seed=93)
+    ctx = LFContext(inp)
+    th = _rows(6, 94)
+    ctx.set_option("count_forms", 1)
+    a, b = ctx.lnprob_pieces(th)
+    got = ctx.lnprob_batch(th)
+    fc = ctx.form_counts()
+    ctx.close()
+    assert fc["table"] + fc["table_noexp"] > 0.8 * 2 * 6 * 300007, fc      # two calls of 6 rows
+    ref = O.lnprob_batch(inp, th)
+    compare_rows(got, ref, inp, th, 1e-12)
+    pa = np.array([O.lnprob(inp, t, pieces=True)[1] for t in th[:3]])
+    np.testing.assert_allclose(a[:3], pa, rtol=1e-12)
+
+
+def test_census_adds_up():
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", 250000, seed=95)
+    ctx = LFContext(inp)
+    th = _rows(40, 96, wide=True)
+    th[3, 8] = 9.0                                 # outside the prior: its terms are counted as skipped
+    ctx.set_option("count_forms", 1)
+    ctx.lnprob_batch(th)
+    fc = ctx.form_counts()
+    ctx.close()
+    src = sum(fc[k] for k in ("general", "general_noexp", "table", "table_noexp", "careful", "skipped"))
+    assert src == 40 * 250000, fc
+    assert fc["skipped"] == 250000
+    assert fc["node_general"] + fc["node_bright"] == 39 * 101 * 101 * 5, fc
