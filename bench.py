@@ -37,32 +37,34 @@ sys.path.insert(0, ROOT)
 
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 (spec; half of the 157.3 fp32 figure of MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
-# EXECUTED fp64 flops per (walker, source) term of the per-source kernel's fast loop, counted from
-# the compiler's assembly (profiles/isa_mix.py -> profiles/r01_isa_mix.txt): FMA = 2, any other fp64
-# VALU instruction = 1.  (The survey's nominal weights - exp/log = 40 flops - would put the same
-# run at ~100 % of peak; DESIGN.md section 4 explains why that figure is not used.)
-FLOPS_PER_TERM = {"free": 54.0, "zevol": 25.0, "fixcomp": 0.0}
-# free variant: terms of (walker, chunk) pairs whose every source has f / f_tau > 37.5 - the decay factor is exactly
-# 1.0 in binary64 - run term_free_noexp (lf_kernels.h): 30 executed flops, 95 issue cycles (profiles/isa_mix.py: the
-# walker loop holds both forms, 84.1 flops and 269 cycles together).  bench.py counts which pairs of the timed
-# workload take it (noexp_terms below) so that `achieved` stays the executed count.
-FLOPS_PER_NODE_FIELD_BRIGHT = 17.0   # grid node-fields of (walker, 256-node chunk) pairs that pass the same test: fc itself
-FLOPS_PER_TERM_NOEXP = 30.0
+# EXECUTED fp64 flops and issue cycles per (walker, source) term / per (walker, node, field) term, by FORM of the term,
+# come from profiles/isa_counts.json, which lumfuncmcmc_amd.build writes from the compiler's assembly of the same
+# sources (profiles/isa_mix.py: FMA = 2 flops, any other fp64 VALU instruction = 1); HOW MANY items took which form
+# in the timed workload comes from the kernel's own census (lf_form_counts).  (The survey's nominal weights - exp/log
+# = 40 flops - would put the same run above peak; DESIGN.md section 4 explains why that figure is not used.)
 SETTLE_STEPS = 20                 # untimed steps after the W warm-up steps, see main()
-CYCLES_PER_TERM_NOEXP = 95.0
-# issue cycles one wave spends per term (fp64 VALU 4, v_rcp/v_rsq_f64 16, 32-bit VALU 2.5; measured
-# rates in profiles/r01_ubench.txt), for the issue-utilisation figure
-CYCLES_PER_TERM = {"free": 174.0, "zevol": 74.0, "fixcomp": 0.0}
-# Piece B runs in the same launch.  FREE, per grid node and walker: one Schechter exponential (23 executed flops)
-# and, per field, exp + rsqrt + log + exp: 70 executed flops - from the compiler's assembly of the unrolled walker
-# loop of the grid part (profiles/isa_mix.py: 36 field terms + 8 per-node tails = 2721 flops >= 36 x 70 + 8 x 23).
-# The other variants' grid parts (one or two exponentials per node) are left out of `achieved`.
-FLOPS_PER_NODE = {"free": 23.0, "fixcomp": 0.0, "zevol": 0.0}
-FLOPS_PER_NODE_FIELD = {"free": 70.0, "fixcomp": 0.0, "zevol": 0.0}
+SOURCE_FORMS = ("general", "general_noexp", "table", "table_noexp")
+NODE_FORMS = ("node_general", "node_bright")
+# the other variants' grid parts (one or two exponentials per node) and the careful path are left out of `achieved`
 # bytes the per-source loop streams per source and launch: logf_i and U_i = 10^(logf_i + 17) (free: the
 # Schechter part is closed-form per walker, so lum_i is not read); lum, z, z^2 (zevol); nothing (fixcomp).
 # SURVEY.md section 8d also counts 16 B for the free variant.
 BYTES_PER_SOURCE = {"free": 16, "fixcomp": 0, "zevol": 24}
+
+
+def isa_counts(launch, variant):
+    """Per-form {flops_per_item, cycles_per_item} of the lf_main instantiation that ran (profiles/isa_counts.json)."""
+    doc = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+    vi = {"free": 0, "fixcomp": 1, "zevol": 2}[variant]
+    if launch.get("kind") == 2:
+        key = "lf_free<%d>" % launch["st"]
+    else:
+        key = "lf_main<%d,%d,%d,%d,%s>" % (vi, launch["st"], launch["tw"], launch["twb"], "true" if launch["compressed"] else "false")
+    forms = doc["kernels"].get(key, {})
+    if launch["compressed"] or not forms:
+        # the compressed-catalogue instantiations carry no markers of their own: price with the direct kernel's forms
+        forms = doc["kernels"].get("lf_main<%d,8,16,16,false>" % vi, {})
+    return key, forms
 
 
 def build_model(variant, nsrc, walkers, device):
@@ -116,68 +118,6 @@ def cpu_baseline_allcores(model, theta, nthreads):
     dt = time.perf_counter() - t0
     return {"value": len(rows) / dt, "unit": "walker-lnprob evals/s", "cores": nthreads, "kind": "port",
             "sample": "%d theta rows of the timed workload over %d OpenMP threads, %.1f s, plain-C scalar loop" % (len(rows), nthreads, dt)}
-
-
-def noexp_terms(ki, blocks, chunk):
-    """(walker, source) terms per launch that take term_free_noexp, averaged over the theta blocks of the timed
-    workload: the kernel's own test, per (walker, chunk of `chunk` flux-sorted sources of a field), on the host.
-    ki: the kernel inputs of THIS rank's context (its catalogue shard when the sources are sharded)."""
-    from lumfuncmcmc_amd.capi import log_flux
-    if ki["variant"] != "free":
-        return 0.0
-    logf = log_flux(np.asarray(ki["lum"]), np.asarray(ki["DLz"]))
-    fi = np.asarray(ki["field_ind"])
-    nf = len(fi) - 1
-    a = (2.0 * ki["fcmin"] - 1.0) ** 2
-    ratio = abs(a / (1.0 - a))
-    k0 = 2 if ki["fix_sch_al"] else 3
-    total = 0.0
-    for th in blocks:
-        aC = th[:, -1]
-        b = -np.sqrt(ratio / aC ** 2)
-        for f in range(nf):
-            x = np.sort(logf[fi[f]:fi[f + 1]])
-            if x.size == 0:
-                continue
-            first = x[::chunk]
-            lens = np.diff(np.append(np.arange(0, x.size, chunk), x.size))
-            Fl = th[:, k0 + f]
-            lF = np.log10(1.0e-17 * Fl)
-            V = 1.0 / (Fl * 10.0 ** b)
-            ok = (aC[:, None] > 0) & (aC[:, None] * (first[None, :] - lF[:, None]) >= 0) & \
-                 (10.0 ** (first[None, :] + 17.0) * V[:, None] > 37.5)
-            total += float((ok * lens[None, :]).sum())
-    return total / max(len(blocks), 1)
-
-
-def bright_nodes(ki, blocks, part=0, parts=1):
-    """(walker, grid node) pairs per launch that take field_sum_bright: the kernel's test per (walker, chunk of 256
-    nodes) - smallest a4 of the chunk times the walker's smallest V above 37.5 - on the host.  Also returns the
-    number of grid nodes this rank integrates (its share of the node chunks when the grid is split)."""
-    S = np.asarray(ki["logL"]).shape[0]
-    nch = -(-S * S // 256)
-    lens = np.minimum(256, S * S - 256 * np.arange(nch))
-    mine = (np.arange(nch) % max(parts, 1)) == part
-    nodes = float(lens[mine].sum())
-    if ki["variant"] != "free":
-        return 0.0, nodes
-    logL = np.asarray(ki["logL"])
-    D = np.log10(4.0 * np.pi * (3.086e24 * np.asarray(ki["DL_zarr"])) ** 2)
-    a4 = (10.0 ** (logL - D[None, :] + 17.0)).ravel()
-    pad = np.full(nch * 256, np.inf)
-    pad[:a4.size] = a4
-    a4min = pad.reshape(nch, 256).min(axis=1)
-    a = (2.0 * ki["fcmin"] - 1.0) ** 2
-    ratio = abs(a / (1.0 - a))
-    k0 = 2 if ki["fix_sch_al"] else 3
-    nf = len(ki["field_ind"]) - 1
-    total = 0.0
-    for th in blocks:
-        aC = th[:, -1]
-        V = 1.0 / (th[:, k0:k0 + nf] * 10.0 ** (-np.sqrt(ratio / aC ** 2))[:, None])
-        ok = (aC[:, None] > 0) & (a4min[None, :] * V.min(axis=1)[:, None] > 37.5)
-        total += float((ok * (lens * mine)[None, :]).sum())
-    return total / max(len(blocks), 1), nodes
 
 
 def self_launch(n):
@@ -300,6 +240,8 @@ class Leg(object):
             ctx.set_option("compress", 1)
         if args.no_specialise:
             ctx.set_option("specialise", 0)
+        if args.no_tables:
+            ctx.set_option("tables", 0)
         self.ndim = ctx.ndim
         # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
         self.theta_all = synth.walkers(args.variant, self.half * nblk, seed=seed).reshape(nblk, self.half, self.ndim)
@@ -348,6 +290,21 @@ def timed(leg, fence, warmup, steps, profile_level):
     return dt, leg.ctx.kernel_times(), out
 
 
+def census(leg, used):
+    """Which form of the term ran how often, per lf_main launch of THIS rank, over the blocks of the timed workload:
+    one extra pass with the kernel's census switched on (outside the timed region; it costs an atomic per
+    (walker, chunk))."""
+    import torch
+    ctx = leg.ctx
+    ctx.set_option("count_forms", 1)
+    for j in used:
+        leg.ev.evaluate_tensor(leg.blocks[j])
+    torch.cuda.synchronize()
+    counts = ctx.form_counts()
+    ctx.set_option("count_forms", 0)
+    return {k: v / float(len(used)) for k, v in counts.items()}
+
+
 def roofline_of(args, leg, model, kt, dt):
     """fp64-VALU roofline of the dominant kernel (lf_main: per-source sum + grid integral in one launch) on THIS rank:
     executed flops of its share of the work / its average launch duration (HIP events on the launch stream)."""
@@ -357,22 +314,19 @@ def roofline_of(args, leg, model, kt, dt):
     avg_ms = k["ms"] / launches if k["launches"] else dt / args.steps / 2 * 1e3   # no events: the whole call
     nsrc, rows = leg.ctx.N, leg.rows_local
     terms = float(nsrc) * rows                                        # (walker, source) terms per launch
-    S, nf = model.size_ln, len(model.Flim)
     used = sorted({(2 * i) % leg.nblk for i in range(args.steps)} | {(2 * i + 1) % leg.nblk for i in range(args.steps)})
-    mine = leg.local_rows(used)
-    t_noexp = 0.0
-    n_bright, nodes = bright_nodes(leg.ki, mine if (variant == "free" and not args.no_specialise and not args.compress) else [],
-                                   *leg.grid_share)
-    grid_flops = float(rows) * nodes * (FLOPS_PER_NODE[variant] + nf * FLOPS_PER_NODE_FIELD[variant])
-    if variant == "free" and not args.no_specialise and not args.compress and rows > 0:
-        # sources per chunk = 256 x the geometry's sources per lane (lfmcmc.hip: GEOS, pick_geometry)
-        st_of = [8, 2, 8, 8, 4, 4, 6, 4, 2]
-        chunks = -(-nsrc // 2048)                       # pick_geometry of lfmcmc.hip
-        auto_st = 8 if (chunks * -(-rows // 16) >= 1024 or chunks * -(-rows // 8) >= 1024 or chunks * -(-rows // 4) >= 384) else 2
-        st = st_of[args.geometry] if args.geometry >= 0 else auto_st
-        t_noexp = noexp_terms(leg.ki, mine, 256 * st)
-        grid_flops -= n_bright * nf * (FLOPS_PER_NODE_FIELD[variant] - FLOPS_PER_NODE_FIELD_BRIGHT)
-    src_flops = (terms - t_noexp) * FLOPS_PER_TERM[variant] + t_noexp * FLOPS_PER_TERM_NOEXP
+    launch = leg.ctx.last_launch()
+    kernel, forms = isa_counts(launch, variant)
+    cnt = census(leg, used) if variant == "free" else {}
+    if variant == "free":
+        src_flops = sum(cnt.get(f, 0.0) * forms[f]["flops_per_item"] for f in SOURCE_FORMS if f in forms)
+        src_cycles = sum(cnt.get(f, 0.0) * forms[f]["cycles_per_item"] for f in SOURCE_FORMS if f in forms)
+        grid_flops = sum(cnt.get(f, 0.0) * forms[f]["flops_per_item"] for f in NODE_FORMS if f in forms)
+        grid_cycles = sum(cnt.get(f, 0.0) * forms[f]["cycles_per_item"] for f in NODE_FORMS if f in forms)
+    else:
+        per = forms.get(variant, {"flops_per_item": 0.0, "cycles_per_item": 0.0})
+        src_flops, src_cycles = terms * per["flops_per_item"], terms * per["cycles_per_item"]
+        grid_flops = grid_cycles = 0.0
     alg_flops = src_flops + grid_flops
     alg_bytes = nsrc * BYTES_PER_SOURCE[variant] + rows * 8 * (leg.ndim + 1)
     traffic = None
@@ -384,17 +338,17 @@ def roofline_of(args, leg, model, kt, dt):
             traffic = None
     ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12
     ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
-    return {"bound": "valu_fp64", "kernel": "lf_main<%s>" % variant, "achieved": ach_tf,
+    return {"bound": "valu_fp64", "kernel": kernel, "achieved": ach_tf,
             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
             "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches, "measured_on": "rank 0",
-            "terms_per_launch": terms, "flops_per_term_executed": FLOPS_PER_TERM[variant],
+            "launch": launch, "terms_per_launch": terms,
             "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
-            "noexp_terms_per_launch": t_noexp, "flops_per_term_noexp": FLOPS_PER_TERM_NOEXP,
-            "bright_grid_nodes_per_launch": n_bright,
+            "items_per_launch_by_form": cnt,
+            "flops_per_item_by_form": {f: forms[f]["flops_per_item"] for f in forms},
+            "cycles_per_item_by_form": {f: forms[f]["cycles_per_item"] for f in forms},
             "terms_per_s": terms / (avg_ms * 1e-3),
-            # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the term loop needs
-            "valu_issue_frac_at_2p4GHz": ((terms - t_noexp) * CYCLES_PER_TERM[variant] + t_noexp * CYCLES_PER_TERM_NOEXP)
-                                         / 64.0 / (avg_ms * 1e-3) / (1024 * 2.4e9),
+            # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the counted forms need
+            "valu_issue_frac_at_2p4GHz": (src_cycles + grid_cycles) / 64.0 / (avg_ms * 1e-3) / (1024 * 2.4e9),
             "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
             "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items() if n != "unused"}}
@@ -420,6 +374,7 @@ def main():
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
     ap.add_argument("--no-extras", action="store_true", help="only the timed loop: no device-sampler / compressed-catalogue / strong-scaling legs (profiling runs)")
     ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
+    ap.add_argument("--no-tables", action="store_true", help="A/B: the general form of the free term only (no g/h tables)")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")

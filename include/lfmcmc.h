@@ -158,6 +158,12 @@ int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
  * real catalogue (the other variants and the compressed catalogue leave it at 0).  Synchronises the device. */
 int lf_form_counts(lf_ctx *ctx, int64_t counts[8]);
 
+/* Shape of the most recent lf_main launch of this context (measurement only): info[0..7] = sources per lane, walkers
+ * per source workgroup and per grid workgroup of the instantiation (template parameters ST, TW, TWB); which kernel ran
+ * (0 lf_main, 1 its compressed-catalogue instantiation, 2 lf_free: the persistent kernel of the free variant);
+ * workgroups in the launch, catalogue chunks, grid chunks, theta rows. */
+int lf_last_launch(const lf_ctx *ctx, int32_t info[8]);
+
 /*
  * Device-resident ensemble sampler: the Goodman & Weare stretch move in its parallel form (two fixed
  * half-ensembles, as emcee 2.x - the API the reference calls - implements it), with theta, lnprob

@@ -35,6 +35,15 @@ def build_library(force=False, verbose=True, extra_flags=()):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    # the per-form instruction counts bench.py prices the kernel with come from the same sources (profiles/isa_mix.py)
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(HERE), "profiles"))
+        import isa_mix
+        isa_mix.write_json(hipcc=hipcc())
+    except Exception as e:                          # measurement aid: never fails the build
+        print("build: profiles/isa_counts.json not refreshed: %s" % e, file=sys.stderr)
+    finally:
+        sys.path.pop(0)
     return LIB
 
 

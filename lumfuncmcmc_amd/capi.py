@@ -43,7 +43,7 @@ EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_ba
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
-           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_form_counts")
+           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_form_counts", "lf_last_launch")
 
 _lib = None
 
@@ -92,6 +92,8 @@ def load():
     lib.lf_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]
     lib.lf_form_counts.restype = ctypes.c_int
     lib.lf_form_counts.argtypes = [ctypes.c_void_p, _c_int64_p]
+    lib.lf_last_launch.restype = ctypes.c_int
+    lib.lf_last_launch.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
     lib.lf_last_error.restype = ctypes.c_char_p
     lib.lf_last_error.argtypes = [ctypes.c_void_p]
     lib.lf_sampler_create.restype = ctypes.c_void_p
@@ -325,6 +327,15 @@ class LFContext(object):
         n = (ctypes.c_int64 * 8)()
         self._check(self._lib.lf_form_counts(self._h, n))
         return {k: int(n[i]) for i, k in enumerate(self.FORM_NAMES)}
+
+    def last_launch(self):
+        """Shape of the most recent lf_main launch: dict st, tw, twb, compressed, workgroups, chunks_a, chunks_b, rows."""
+        n = (ctypes.c_int32 * 8)()
+        self._check(self._lib.lf_last_launch(self._h, n))
+        d = dict(zip(("st", "tw", "twb", "kind", "workgroups", "chunks_a", "chunks_b", "rows"), (int(v) for v in n)))
+        d["compressed"] = int(d["kind"] == 1)
+        d["kernel"] = "lf_free<%d>" % d["st"] if d["kind"] == 2 else "lf_main"
+        return d
 
     def set_option(self, key, value):
         self._check(self._lib.lf_set_option(self._h, key.encode(), int(value)))

@@ -1,0 +1,296 @@
+// lf_free.h - the FREE variant's lnprob work (pieces A and B) in PERSISTENT 512-thread workgroups (gfx950).
+//
+// Why this shape (all measured on MI355X):
+//  * One wave issues one fp64 VALU instruction per ~8.5 cycles however many independent chains it has; a SIMD needs
+//    4 resident waves to reach its 3.4 cycles per instruction (profiles/r01_ubench.txt).  So: <= 128 VGPRs, 16 waves
+//    per CU.
+//  * The table-driven form of the term (lf_kernels.h: table_lookup / table_terms) needs 33 KB of tables in LDS.  Eight
+//    waves share one copy: 512-thread workgroups, two per CU (70 KB of LDS each).
+//  * A workgroup that lives for one item pays its prologue (tables, items, walker constants: 5k cycles) and its
+//    reduction every ~35k cycles (tools/stamps.py).  Persistent workgroups load the tables ONCE, serve ONE tile of PTW
+//    walkers for their whole life (its constants for all fields: 4.5 KB of LDS, loaded once), and pull items from the
+//    tile's queues; the next item's sources are already on their way into registers while the current one is summed.
+//
+// Items of a tile: node chunks of the integration grid (piece B, 512 nodes each; longer, so served first) and catalogue
+// chunks (piece A, 512 ST flux-neighbouring sources of one field).  Catalogue chunks are dealt to eight queues per
+// tile, one per XCD (workgroups ask for their XCC id), so that the sixteen tiles' reads of a chunk meet in one L2; an
+// empty queue steals from the next.  lf_prepare zeroes the counters of the launch that follows it.
+//
+// Results: every (walker, chunk) partial sum goes to its own slot of partA / partB and lf_finalize adds them in a fixed
+// order, as in lf_main - the bits depend on the launch geometry (ST), not on which workgroup served which item.
+#pragma once
+#include "lf_kernels.h"
+
+namespace lf {
+
+constexpr int PB = 512;      // threads per persistent workgroup: 8 waves
+constexpr int PTW = 8;       // walkers per tile
+constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalogue queues of XCD 0..7
+
+// 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
+// (eight columns per lane, stride 64) and runs one 64-lane tree.  Fixed order.
+__device__ __forceinline__ void reduce_store512(const double* __restrict__ red, int nw, double* __restrict__ out,
+                                                size_t stride, int w0, int chunk) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (w < nw) {
+        const double* row = red + w * PB + lane;
+        double s0 = (row[0] + row[64]) + (row[128] + row[192]);
+        double s1 = (row[256] + row[320]) + (row[384] + row[448]);
+        const double s = wave_sum(s0 + s1);
+        if (lane == 0) out[(size_t)(w0 + w) * stride + chunk] = s;
+    }
+}
+
+struct FreeArgs {
+    int B, ntiles;            // theta rows, tiles of PTW walkers
+    int nchA, nchB;           // catalogue chunks (512 ST sources), node chunks (512 nodes)
+    int tile_stride;          // workgroup g serves tiles (g / 8) % ntiles, + tile_stride, ... (normally just one)
+    int skip_grid;
+    int* queues;              // [ntiles][QSTRIDE]
+    double* partA;            // [B][nchA]
+    double* partB;            // [B][nchB]
+};
+
+// CENSUS: the instantiation that counts which form of the term ran (lf_form_counts); the product one has no trace of it
+template <int ST, bool CENSUS>
+__global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeArrays na, const double* __restrict__ wrec,
+                                                 const int* __restrict__ wmode, FreeArgs fa) {
+    __shared__ MathTables tab;
+    __shared__ TermTables tt;
+    __shared__ __attribute__((aligned(16))) double red[(ST > PTW ? ST : PTW) * PB];   // reduction buffer = staging area of the items
+    __shared__ __attribute__((aligned(16))) double wfc[PTW * MAXF * 8];   // per (walker, field): aC, V, cA, cY, {mode, klo, khi, kne, kaC}
+    __shared__ __attribute__((aligned(16))) double wsc[PTW * 8];          // per walker: L*, c0, c1, Q, alpha_C
+    __shared__ int sitem[2];
+    const int tid = threadIdx.x;
+    // ---- once per workgroup: the tables, and which XCD we are on
+    for (int i = tid; i < 256; i += PB) {
+        tab.logt[i] = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * i);
+        tab.expt[i] = EXP_TABLE[i];
+    }
+    load_term_tables<PB>(&tt);
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int myq = (int)(xcc & 7u);
+#ifdef LF_STAMPS
+    unsigned long long* stamp = kc.stamps ? kc.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+    int nitems_done = 0;
+#endif
+
+#pragma unroll 1
+    for (int tile = ((int)blockIdx.x >> 3) % fa.ntiles; tile < fa.ntiles; tile += fa.tile_stride) {
+        const int w0 = tile * PTW;
+        const int nw = min(PTW, fa.B - w0);
+        int* __restrict__ q = fa.queues + tile * QSTRIDE;
+        // next item of this tile: a node chunk while there are any (item = chunk), then a catalogue chunk of our XCD's
+        // queue, or of the next queue that still has some (item = nchB + chunk); -1 = the tile is done
+        auto grab = [&]() -> int {
+            if (!fa.skip_grid && fa.nchB > 0) {
+                const int i = atomicAdd(q, 1);
+                if (i < fa.nchB) return i;
+            }
+            for (int d = 0; d < 8; ++d) {
+                const int qq = (myq + d) & 7;
+                const int lo = (int)(((long long)qq * fa.nchA) >> 3), hi = (int)(((long long)(qq + 1) * fa.nchA) >> 3);
+                if (hi <= lo) continue;
+                const int i = atomicAdd(q + 1 + qq, 1);
+                if (i < hi - lo) return fa.nchB + lo + i;
+            }
+            return -1;
+        };
+        __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
+        if (tid == 0) sitem[0] = grab();
+        // the tile's walker constants, all fields (64 B per (walker, field)), once
+        if (tid < nw * MAXF) {
+            const int w = tid / MAXF, f = tid - w * MAXF;
+            double* d = wfc + tid * 8;
+            int* di = reinterpret_cast<int*>(d + 4);
+            if (f < kc.nf) {
+                // slot order of the record's own field block (F_V = 1, F_CA = 2, F_CY = 3), alpha_C in the slot of lF
+                const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+                const int* __restrict__ km = wmode + ((size_t)(w0 + w) * MAXF + f) * WM;
+                d[0] = r[R_ALPHAC];
+                d[F_V] = r[RF(f, F_V)];
+                d[F_CA] = r[RF(f, F_CA)];
+                d[F_CY] = r[RF(f, F_CY)];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) di[i] = km[i];
+            }
+        }
+        if (tid >= PB - PTW * 8) {                // (the last 64 threads: walker w, scalar slot j)
+            const int t = tid - (PB - PTW * 8), w = t >> 3, j = t & 7;
+            if (w < nw) wsc[t] = wrec[(size_t)(w0 + w) * REC + j];
+        }
+        __syncthreads();
+        int item = sitem[0];
+        // (No register prefetch of the next item: it would cost 16 VGPRs across the whole walker loop, and with 128 per
+        // wave that means scratch traffic inside the loop - measured 4x slower.  The other workgroup of the CU computes
+        // while this one waits for its item at switch-in.)
+        auto fetch = [&](int w, int fld) {        // uniform LDS address: broadcast reads
+            const double2* __restrict__ p = reinterpret_cast<const double2*>(wfc + (w * MAXF + fld) * 8);
+            const double2 a = p[0], b = p[1];
+            const int4 k = *reinterpret_cast<const int4*>(p + 2);
+            const int k4 = *reinterpret_cast<const int*>(p + 3);
+            return WalkerK{a.x, b.x, b.y, a.y, __builtin_amdgcn_readfirstlane(k.x), __builtin_amdgcn_readfirstlane(k.y),
+                           __builtin_amdgcn_readfirstlane(k.z), __builtin_amdgcn_readfirstlane(k.w), __builtin_amdgcn_readfirstlane(k4)};
+        };
+
+#pragma unroll 1
+        while (item >= 0) {
+            __syncthreads();                      // [D] the previous item's reduction has read `red`
+            if (tid == 0) sitem[0] = grab();
+            if (item >= fa.nchB) {
+                // ================= catalogue chunk: piece A =================
+                const int c = item - fa.nchB;
+                const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
+                const int kfirst = sa.chunk_keys[4 * c], klast = sa.chunk_keys[4 * c + 1], kamax = sa.chunk_keys[4 * c + 2];
+                // switch in: the chunk's sources, coalesced (instruction k of a wave reads 512 contiguous bytes), via LDS
+#pragma unroll
+                for (int k = 0; k < ST; ++k) red[k * PB + tid] = sa.a1[(size_t)s0 + min(k * PB + tid, n - 1)];
+                __syncthreads();                  // [A]
+                double x[ST];
+                {
+                    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(red + tid * ST);
+#pragma unroll
+                    for (int k = 0; k < ST / 2; ++k) {
+                        const double2 a = x2[k];
+                        x[2 * k] = a.x;
+                        x[2 * k + 1] = a.y;
+                    }
+                }
+                const int next = sitem[0];
+                __syncthreads();                  // [B] the staging area becomes the reduction buffer again
+                // slots past the end of the chunk hold copies of its last source
+                const int npad = ST - min(max(n - tid * ST, 0), ST);
+                // ---- pass 1: the walkers whose (walker, chunk) pair takes the table-driven form (the bulk)
+                int rest = 0;                     // bit w: walker w needs pass 2 (wave-uniform)
+#pragma unroll 1
+                for (int w = 0; w < nw; ++w) {
+                    const WalkerK p = fetch(w, fld);
+                    double acc = 0.0;
+                    if (p.mode < MODE_SKIP && p.mode != MODE_SLOW && kc.tables && kfirst >= p.klo && klast <= p.khi && p.kac <= kamax) {
+                        TabCoef C;
+                        if (kc.specialise && kfirst >= p.kne) {
+                            asm volatile("; LF_BEGIN table_noexp items=%0" ::"n"(ST));
+                            table_lookup<ST>(C, x, p, true, &tt);
+                            acc = table_terms<ST, true>(C, x, npad);
+                            asm volatile("; LF_END table_noexp");
+                            if (CENSUS && kc.forms && tid == 0) atomicAdd(kc.forms + FORM_TABLE_NOEXP, (unsigned long long)n);
+                        } else {
+                            asm volatile("; LF_BEGIN table items=%0" ::"n"(ST));
+                            table_lookup<ST>(C, x, p, false, &tt);
+                            acc = table_terms<ST, false>(C, x, npad);
+                            asm volatile("; LF_END table");
+                            if (CENSUS && kc.forms && tid == 0) atomicAdd(kc.forms + FORM_TABLE, (unsigned long long)n);
+                        }
+                    } else if (p.mode < MODE_SKIP) {
+                        rest |= 1 << w;
+                    } else if (CENSUS && kc.forms && tid == 0) {
+                        // -inf already (outside the prior, or the brightest source underflows): nothing to sum
+                        atomicAdd(kc.forms + FORM_SKIPPED, (unsigned long long)n);
+                    }
+                    red[w * PB + tid] = acc;
+                }
+                // ---- pass 2 (rare at the catalogue sizes this kernel serves): pairs outside the tables' reach - the
+                // sparse tails of a field, extreme walkers - in the general form (lf_math.h: table exp / log, one rsqrt
+                // seed), and walkers that may underflow on the careful path (device-library math, per-term checks, -inf
+                // poisoning).  Sources re-read from memory in a rolled loop: none of this may claim registers next to
+                // the table form's.
+                if (rest) {
+                    const double a1_first = sa.a1[s0], u_first = sa.U[s0];      // sorted by flux: the chunk's faintest
+#pragma unroll 1
+                    for (int w = 0; w < nw; ++w) {
+                        if (!((rest >> w) & 1)) continue;
+                        const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+                        const int mode = wmode[((size_t)(w0 + w) * MAXF + fld) * WM];
+                        double acc = 0.0;
+                        int form;
+                        if (mode == MODE_SLOW) {
+                            form = FORM_CAREFUL;
+                            const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
+                                           r[RF(fld, F_LF)], r[RF(fld, F_V)], kc.lnom0_src[fld], 0.0};
+#pragma unroll 1
+                            for (int i = tid; i < n; i += PB) {
+                                const size_t g = (size_t)s0 + i;
+                                acc += term_free_careful(wf, sa.lum[g], sa.a1[g], sa.P[g], sa.U[g]);
+                            }
+                        } else {
+                            WFree wf{};
+                            wf.alphaC = r[R_ALPHAC];
+                            wf.cA = r[RF(fld, F_CA)];
+                            wf.V = r[RF(fld, F_V)];
+                            const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
+                            if (upper && u_first * wf.V > 37.5) {
+                                form = FORM_GENERAL_NOEXP;
+#pragma unroll 1
+                                for (int i = tid; i < n; i += PB) {
+                                    asm volatile("; LF_BEGIN general_noexp items=1");
+                                    acc += term_free_noexp(wf, sa.a1[(size_t)s0 + i], &tab);
+                                    asm volatile("; LF_END general_noexp");
+                                }
+                            } else {
+                                form = FORM_GENERAL;
+#pragma unroll 1
+                                for (int i = tid; i < n; i += PB) {
+                                    asm volatile("; LF_BEGIN general items=1");
+                                    acc += term_free_fast(wf, sa.a1[(size_t)s0 + i], sa.U[(size_t)s0 + i], &tab);
+                                    asm volatile("; LF_END general");
+                                }
+                            }
+                        }
+                        if (CENSUS && kc.forms && tid == 0) atomicAdd(kc.forms + form, (unsigned long long)n);
+                        red[w * PB + tid] = acc;
+                    }
+                }
+                __syncthreads();                  // [C]
+                reduce_store512(red, nw, fa.partA, (size_t)fa.nchA, w0, c);
+                item = next;
+            } else {
+                // ================= node chunk: piece B =================
+                const int c = item;
+                const bool valid = c * PB + tid < na.nnodes;
+                const int g = min(c * PB + tid, na.nnodes - 1);
+                const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0, a3 = na.a3[g], a4 = na.a4[g];
+                const double a4min = fmin(na.a4min[2 * c], na.a4min[min(2 * c + 1, (na.nnodes + BLOCK - 1) / BLOCK - 1)]);   // wave-uniform
+                __syncthreads();                  // [A] (sitem)
+                const int next = sitem[0];
+                const int nodes_here = min(PB, na.nnodes - c * PB);
+#pragma unroll 1
+                for (int w = 0; w < nw; ++w) {
+                    const double* __restrict__ sc = wsc + w * 8;
+                    const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (w * MAXF) * 8 + 4));
+                    double val = 0.0;
+                    if (mode != MODE_SKIP) {      // outside the prior: not evaluated
+                        const double T = fexp_c(fma(uni(sc[R_C1]), G - uni(sc[R_LSTAR]), uni(sc[R_C0])) - PG * uni(sc[R_Q]), &tab);
+                        const double alphaC = uni(sc[R_ALPHAC]);
+                        // per-field constants of this walker as the grid forms expect them: r[RF(f, F_CA)], r[RF(f, F_V)]
+                        const double* __restrict__ r = wfc + w * MAXF * 8 - 8;   // RF(f, slot) = 8 + 8 f + slot
+                        double vmin = r[RF(0, F_V)];
+                        for (int f = 1; f < kc.nf; ++f) vmin = fmin(vmin, r[RF(f, F_V)]);
+                        const bool bright = kc.specialise && alphaC > 0.0 && a4min * uni(vmin) > 37.5;
+                        if (CENSUS && kc.forms && tid == 0)
+                            atomicAdd(kc.forms + (bright ? FORM_NODE_BRIGHT : FORM_NODE_GENERAL), (unsigned long long)(nodes_here * kc.nf));
+                        const double s = field_sum_nf(kc, r, alphaC, a3, a4, &tab, bright);
+                        val = W * T * s;
+                    }
+                    red[w * PB + tid] = val;
+                }
+                __syncthreads();                  // [C]
+                reduce_store512(red, nw, fa.partB, (size_t)fa.nchB, w0, c);
+                item = next;
+            }
+#ifdef LF_STAMPS
+            ++nitems_done;
+#endif
+        }
+    }
+#ifdef LF_STAMPS
+    if (stamp && tid == 0) {
+        stamp[1] = __builtin_amdgcn_s_memtime();
+        stamp[2] = (unsigned long long)nitems_done;
+        stamp[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+}  // namespace lf

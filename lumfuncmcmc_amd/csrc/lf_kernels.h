@@ -83,6 +83,10 @@ struct KConst {
     // optional census of which form of the term / node ran (bench.py's flop accounting, tests): terms or node-fields
     // added per (walker, chunk) by one lane; NULL = off (the default: no atomics on the path)
     unsigned long long* forms;
+#ifdef LF_STAMPS
+    // diagnostic build (tools/stamps.py): s_memtime at four points of every source workgroup; never in the product
+    unsigned long long* stamps;
+#endif
     // per-field sums for the closed-form part of piece A:
     //   sum_i ln TrueLumFunc_i = n (ln ln10 + ln10 phi*) + c1 (sum(lum_i - 42) - n (L* - 42)) - Q sum P_i
     double slc[MAXF];         // sum (lum_i - 42)
@@ -247,9 +251,11 @@ __device__ __forceinline__ int key_floor(double v) {
 // lf_finalize resets the count.
 __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const double* __restrict__ theta, int B,
                                                  double* __restrict__ wrec, int* __restrict__ wstat,
-                                                 int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list) {
+                                                 int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
+                                                 int* __restrict__ queue, int nqueue) {
     __shared__ double sth[8][16];
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt < nqueue) queue[gt] = 0;                  // item counters of the lf_free launch that follows (8 B threads >= 9 B / 8)
     const int wq = gt >> 3, f = gt & 7, grp = threadIdx.x >> 3;
     const bool live = wq < B;
     const int w = live ? wq : B - 1;                 // idle groups replay the last walker, write nothing
@@ -417,6 +423,12 @@ __device__ __forceinline__ double ln_fc_fast(double num, const MathTables* __res
     return flog_half(fma(num, frsqrt(s), 1.0), tab);
 }
 
+// a wave-uniform double that arrived in a VGPR (broadcast LDS read) -> SGPR pair: VALU instructions take it as a scalar
+// operand and it stops occupying a vector register per lane
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 struct WFree {   // wave-uniform walker constants of one (walker, field)
     double Lstar, c0f, c1, Q, alphaC, lF, V, lnom0, cA;
 };
@@ -478,17 +490,34 @@ __device__ __forceinline__ double lnT_zevol(const WZ& w, double lum, double z, d
 }
 
 // ----------------------------------------------------------------------------------------------
-// block reduction: red[nw][256] (LDS) -> out[(w0 + w) * stride + chunk]
+// block reduction: red[nw][256] (LDS) -> out[(w0 + w) * stride + chunk], nw <= 16.
+// All walkers at once: thread t = (walker t >> 4, column group t & 15) adds its 16 columns (stride 16: consecutive
+// lanes read consecutive doubles), then the 16 lanes of a walker combine with four xor-shuffles inside their
+// 16-lane row.  Fixed order: the bits depend on the launch geometry only.  (The first version gave each wave four
+// walkers in turn, a 64-lane shuffle tree each: 3.3k cycles of dependent latency at the end of every workgroup,
+// 8 % of its lifetime, measured with tools/stamps.py.)
 // ----------------------------------------------------------------------------------------------
 // widx: optional list of walker indices (the tile is widx[0 .. nw-1] instead of w0 .. w0+nw-1)
 __device__ __forceinline__ void reduce_store(const double* __restrict__ red, int nw, double* __restrict__ out,
                                              size_t stride, int w0, int chunk, const int* __restrict__ widx = nullptr) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int w = wave; w < nw; w += BLOCK / 64) {
-        const double* row = red + w * BLOCK;
-        double s = (row[lane] + row[lane + 64]) + (row[lane + 128] + row[lane + 192]);
-        s = wave_sum(s);
-        if (lane == 0) out[(size_t)(widx ? widx[w] : w0 + w) * stride + chunk] = s;
+    static_assert(BLOCK == 256, "16 walkers x 16 column groups");
+    for (int wb = 0; wb < nw; wb += 16) {            // (tiles are at most 16 walkers: one pass)
+        const int w = wb + (threadIdx.x >> 4), j = threadIdx.x & 15;
+        const double* row = red + (w < nw ? w : 0) * BLOCK + j;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            s0 += row[16 * i];
+            s1 += row[16 * (i + 1)];
+            s2 += row[16 * (i + 2)];
+            s3 += row[16 * (i + 3)];
+        }
+        double sum = (s0 + s1) + (s2 + s3);
+        sum += __shfl_xor(sum, 8, 16);
+        sum += __shfl_xor(sum, 4, 16);
+        sum += __shfl_xor(sum, 2, 16);
+        sum += __shfl_xor(sum, 1, 16);
+        if (j == 0 && w < nw) out[(size_t)(widx ? widx[w] : w0 + w) * stride + chunk] = sum;
     }
 }
 
@@ -506,6 +535,7 @@ struct SrcArrays {
     const int* chunk_len;
     const int* chunk_field;
     const int* chunk_keys;   // FREE, real catalogue: per chunk {kfirst, klast, kamax, -} (lfmcmc.hip: get_chunks), else NULL
+    int* queue;              // FREE, real catalogue: the eight per-XCD item counters of the persistent workgroups
 };
 
 // CMP = the items are the pseudo-sources of the compressed catalogue (lfmcmc.hip: build_compressed): each
@@ -592,24 +622,29 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 if (mode >= MODE_SKIP) {
                     // -inf already: nothing to sum
                 } else if (noexp) {
+                    if (!CMP && !IDX) asm volatile("; LF_BEGIN general_noexp items=%0" ::"n"(ST));
 #pragma unroll
                     for (int k = 0; k < ST; ++k) {
                         const double term = term_free_noexp(wf, a1[k], &tab);
                         acc = CMP ? fma(term, wgt[k], acc) : acc + term;
                     }
+                    if (!CMP && !IDX) asm volatile("; LF_END general_noexp");
                 } else {
+                    if (!CMP && !IDX) asm volatile("; LF_BEGIN general items=%0" ::"n"(ST));
 #pragma unroll
                     for (int k = 0; k < ST; ++k) {
                         const double term = term_free_fast(wf, a1[k], uu[k], &tab);
                         acc = CMP ? fma(term, wgt[k], acc) : acc + term;
                     }
+                    if (!CMP && !IDX) asm volatile("; LF_END general");
                 }
             } else if (VARIANT == LF_FIXCOMP) {
                 // nothing left per source: piece A is the closed form in wbase
             } else {
                 const WZ wz = nz;
                 nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
-                if (mode < MODE_SKIP)
+                if (mode < MODE_SKIP) {
+                if (!CMP) asm volatile("; LF_BEGIN zevol items=%0" ::"n"(ST));
 #pragma unroll
                 for (int k = 0; k < ST; ++k) {
                     const double Ls = CMP ? quad_comp(wz.aL, wz.bL, wz.cL, a1[k])
@@ -618,6 +653,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                     // fexp_t underflows to 0 by itself - no clamps
                     const double v = fexp_t(LF_LN10 * (lum[k] - Ls), &tab);
                     acc = fma(-v, wgt[k], acc);             // everything else of the term is in wbase
+                }
+                if (!CMP) asm volatile("; LF_END zevol");
                 }
             }
         } else if (CMP) {
@@ -674,7 +711,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
 }
 
 // ----------------------------------------------------------------------------------------------
-// piece A, FREE variant, real catalogue: the table-driven form of the term.
+// piece A, FREE variant, real catalogue: the table-driven form of the term (used by lf_free.h).
 //
 // After the hoisting of the header comment the term of (walker w, source i of field f) is
 //     ln fc(num) / (1 - e^(-f/f_tau)) = g(num_i) h(y_i),   num_i = alpha_C x_i + cA_wf,   y_i = x_i + cY_wf,   x_i = logf_i
@@ -688,159 +725,103 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
 // (walker, field) and get_chunks (chunk) have rounded conservatively: the chunk's fluxes inside both tables with
 // room for the margins, and alpha_C times the widest lane of the chunk within the margin.  Pairs that may not
 // (the sparse bright and faint tails of a field, tiny catalogues, extreme walkers) take the general form.
+//
 // ----------------------------------------------------------------------------------------------
-template <int ST, bool NOEXP, bool MASK>
-__device__ __forceinline__ double table_terms(const double (&x)[ST], int nv, double aC, double cA, double cY,
-                                              const TermTables* __restrict__ tt) {
+struct TabCoef {       // one lane's pieces of g and h for one walker, and the affine maps into their local coordinates
+    double cg[8], ch[8];
+    double sa, sc, dy;
+};
+struct WalkerK {       // wave-uniform constants of one (walker, field), read from the LDS copy
+    double aC, cA, cY, V;
+    int mode, klo, khi, kne, kac;
+};
+
+template <int ST>
+__device__ __forceinline__ void table_lookup(TabCoef& C, const double (&x)[ST], const WalkerK& p, bool noexp,
+                                             const TermTables* __restrict__ tt) {
     const double xc = x[ST / 2];
     // g: binade of v = |num| + 1 and its top G_BITS mantissa bits
-    const double numc = fma(aC, xc, cA);
+    const double numc = fma(p.aC, xc, p.cA);
     const double v = fabs(numc) + 1.0;
     const int hi = __double2hiint(v) & (int)(0xffffffffu << (20 - G_BITS));
     const double vlo = __hiloint2double(hi, 0);
     const bool neg = numc < 0.0;
     int pg = (hi >> (20 - G_BITS)) - (0x3ff << G_BITS) + (neg ? G_NPOS : 0);
     pg = min(max(pg, 0), G_N - 1);
-    const double sa = neg ? -aC : aC;                         // t_i = |num_i| + 1 - v_lo = sa x_i + sc
-    const double sc = (neg ? -cA : cA) + (1.0 - vlo);
-    double cg[8], ch[8];
-    {
-        const double2* __restrict__ g2 = reinterpret_cast<const double2*>(tt->g) + pg * 4;
+    C.sa = neg ? -p.aC : p.aC;                                // t_i = |num_i| + 1 - v_lo = sa x_i + sc
+    C.sc = (neg ? -p.cA : p.cA) + (1.0 - vlo);
+    const double2* __restrict__ g2 = reinterpret_cast<const double2*>(tt->g) + pg * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double2 t = g2[q];
-            cg[2 * q] = t.x;
-            cg[2 * q + 1] = t.y;
-        }
+    for (int q = 0; q < 4; ++q) {
+        const double2 t = g2[q];
+        C.cg[2 * q] = t.x;
+        C.cg[2 * q + 1] = t.y;
     }
-    double dy = 0.0;
-    if (!NOEXP) {
-        const double yq = fmin(fmax((xc + cY - H_LO) * (double)H_INV, 0.0), (double)(H_N - 1));
-        const int ph = (int)yq;                                // floor: yq >= 0
-        dy = cY - (H_LO + (double)ph * (1.0 / H_INV));         // t_i = y_i - y_lo = x_i + dy
+    C.dy = 0.0;
+    if (!noexp) {                                             // (wave-uniform)
+        const double yq = fmin(fmax((xc + p.cY - H_LO) * (double)H_INV, 0.0), (double)(H_N - 1));
+        const int ph = (int)yq;                               // floor: yq >= 0
+        C.dy = p.cY - (H_LO + (double)ph * (1.0 / H_INV));    // t_i = y_i - y_lo = x_i + dy
         const double2* __restrict__ h2 = reinterpret_cast<const double2*>(tt->h) + ph * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double2 t = h2[q];
-            ch[2 * q] = t.x;
-            ch[2 * q + 1] = t.y;
+            C.ch[2 * q] = t.x;
+            C.ch[2 * q + 1] = t.y;
         }
     }
-    // marker for profiles/isa_mix.py: the basic block that holds it is this form's unrolled term loop
-    if (NOEXP) { if (MASK) asm volatile("; LF_FORM table_noexp_masked"); else asm volatile("; LF_FORM table_noexp"); }
-    else { if (MASK) asm volatile("; LF_FORM table_masked"); else asm volatile("; LF_FORM table"); }
-    double acc = 0.0;
-#pragma unroll
-    for (int k = 0; k < ST; ++k) {
-        const double pgv = horner7(cg, fma(sa, x[k], sc));
-        if (NOEXP) {
-            acc += MASK ? (k < nv ? pgv : 0.0) : pgv;
-        } else {
-            const double phv = horner7(ch, x[k] + dy);
-            if (MASK) acc += k < nv ? pgv * phv : 0.0;
-            else acc = fma(pgv, phv, acc);
-        }
-    }
-    return acc;
 }
 
-template <int ST, int TW>
-__device__ __forceinline__ void srcsum_free(const KConst& kc, const SrcArrays& sa, const double* __restrict__ wrec,
-                                            const int* __restrict__ wmode, int c, int w0, int nw,
-                                            double* __restrict__ partial, int pstride, const MathTables& tab,
-                                            const TermTables& tt, double* __restrict__ red) {
-    const int tid = threadIdx.x;
-    const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
-    const int kfirst = sa.chunk_keys[4 * c], klast = sa.chunk_keys[4 * c + 1], kamax = sa.chunk_keys[4 * c + 2];
-    // sources are sorted by flux inside a field: the chunk's first is its faintest
-    const double a1_first = sa.a1[s0], u_first = sa.U[s0];
-    const bool full = n == ST * BLOCK;
-    // lane tid holds the ST flux-neighbours s0 + tid ST .. (a 64-B line per lane); slots past the end of the chunk
-    // replay its last source and are masked out of the sums
-    const int nv = min(max(n - tid * ST, 0), ST);
-    double x[ST], uu[ST];
+// Sum of the lane's ST terms.  Horner steps go coefficient by coefficient ACROSS the ST sources: 2 ST independent FMA
+// chains in flight (a source's own chain is 7 dependent FMAs).  npad = slots of this lane past the end of the chunk:
+// they hold copies of the chunk's last source, so they all evaluate to the value of slot ST - 1, which is taken
+// out again (exact for whole lanes: 8 t - 8 t; one rounding otherwise).
+template <int ST, bool NOEXP>
+__device__ __forceinline__ double table_terms(const TabCoef& C, const double (&x)[ST], int npad) {
+    // Sources in batches of CH: g and h of a batch together, 2 CH independent FMA chains in flight (a source's own
+    // chain is 7 dependent FMAs).  CH = 4: with the 4 waves per SIMD the kernel is sized for (<= 128 VGPRs) a wave
+    // issues every fourth slot, so two steps of one chain are ~100 cycles apart anyway; all ST sources at once would
+    // cost 24 more VGPRs.
+    constexpr int CH = ST < 4 ? ST : 4;
+    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+    double last = 0.0;
 #pragma unroll
-    for (int k = 0; k < ST; ++k) {
-        const size_t g = (size_t)s0 + min(tid * ST + k, n - 1);
-        x[k] = sa.a1[g];
-        uu[k] = sa.U[g];
-    }
-    struct WP {
-        double aC, cA, cY, V;
-        int mode, klo, khi, kne, kac;
-    };
-    auto fetch = [&](int w) {
-        const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
-        const int* __restrict__ km = wmode + ((size_t)(w0 + w) * MAXF + fld) * WM;
-        return WP{r[R_ALPHAC], r[RF(fld, F_CA)], r[RF(fld, F_CY)], r[RF(fld, F_V)], km[M_MODE], km[M_KLO], km[M_KHI], km[M_KNE], km[M_KAC]};
-    };
-    // the NEXT walker's constants are fetched (scalar loads) while the current one computes
-    WP nx = fetch(0);
-#pragma unroll 1
-    for (int w = 0; w < nw; ++w) {
-        const WP cur = nx;
-        nx = fetch(min(w + 1, nw - 1));
-        const int mode = __builtin_amdgcn_readfirstlane(cur.mode);
-        double acc = 0.0;
-        int form = FORM_SKIPPED;
-        if (mode == MODE_SLOW) {
-            // careful path (rare): device-library math, per-term underflow checks, -inf poisoning; items re-read
-            // from memory in a rolled loop so that it adds no register pressure
-            form = FORM_CAREFUL;
-            const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
-            const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
-                           r[RF(fld, F_LF)], r[RF(fld, F_V)], kc.lnom0_src[fld], 0.0};
-#pragma unroll 1
-            for (int k = 0; k < ST; ++k) {
-                const int i = k * BLOCK + tid;
-                if (i >= n) break;
-                const size_t g = (size_t)s0 + i;
-                acc += term_free_careful(wf, sa.lum[g], sa.a1[g], sa.P[g], sa.U[g]);
-            }
-        } else if (mode >= MODE_SKIP) {
-            // -inf already (outside the prior, or the brightest source underflows): nothing to sum
-        } else {
-            const bool tab_ok = kc.tables && kfirst >= __builtin_amdgcn_readfirstlane(cur.klo) &&
-                                klast <= __builtin_amdgcn_readfirstlane(cur.khi) &&
-                                __builtin_amdgcn_readfirstlane(cur.kac) <= kamax;
-            if (tab_ok) {
-                const bool ne = kc.specialise && kfirst >= __builtin_amdgcn_readfirstlane(cur.kne);
-                form = ne ? FORM_TABLE_NOEXP : FORM_TABLE;
-                if (full) acc = ne ? table_terms<ST, true, false>(x, nv, cur.aC, cur.cA, cur.cY, &tt)
-                                   : table_terms<ST, false, false>(x, nv, cur.aC, cur.cA, cur.cY, &tt);
-                else acc = ne ? table_terms<ST, true, true>(x, nv, cur.aC, cur.cA, cur.cY, &tt)
-                              : table_terms<ST, false, true>(x, nv, cur.aC, cur.cA, cur.cY, &tt);
-            } else {
-                // general form (lf_math.h: table exp / log, one rsqrt seed), with its own chunk-level shortcut
-                WFree wf{};
-                wf.alphaC = cur.aC;
-                wf.cA = cur.cA;
-                wf.V = cur.V;
-                const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
-                if (upper && u_first * wf.V > 37.5) {
-                    form = FORM_GENERAL_NOEXP;
-                    asm volatile("; LF_FORM general_noexp");
+    for (int k0 = 0; k0 < ST; k0 += CH) {
+        double t[CH], u[CH], p[CH], q[CH];
 #pragma unroll
-                    for (int k = 0; k < ST; ++k) {
-                        const double term = term_free_noexp(wf, x[k], &tab);
-                        acc += k < nv ? term : 0.0;
-                    }
-                } else {
-                    form = FORM_GENERAL;
-                    asm volatile("; LF_FORM general");
+        for (int k = 0; k < CH; ++k) {
+            t[k] = fma(C.sa, x[k0 + k], C.sc);
+            if (!NOEXP) u[k] = x[k0 + k] + C.dy;
+        }
 #pragma unroll
-                    for (int k = 0; k < ST; ++k) {
-                        const double term = term_free_fast(wf, x[k], uu[k], &tab);
-                        acc += k < nv ? term : 0.0;
-                    }
-                }
+        for (int k = 0; k < CH; ++k) {
+            p[k] = fma(C.cg[7], t[k], C.cg[6]);
+            if (!NOEXP) q[k] = fma(C.ch[7], u[k], C.ch[6]);
+        }
+#pragma unroll
+        for (int j = 5; j >= 0; --j) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                p[k] = fma(p[k], t[k], C.cg[j]);
+                if (!NOEXP) q[k] = fma(q[k], u[k], C.ch[j]);
             }
         }
-        if (kc.forms && tid == 0) atomicAdd(kc.forms + form, (unsigned long long)n);
-        red[w * BLOCK + tid] = acc;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (NOEXP) {
+                acc4[k & 3] += p[k];
+                if (k0 + k == ST - 1) last = p[k];
+            } else if (k0 + k == ST - 1) {
+                last = p[k] * q[k];
+                acc4[k & 3] += last;
+            } else {
+                acc4[k & 3] = fma(p[k], q[k], acc4[k & 3]);
+            }
+        }
+        if (k0 + CH < ST) __builtin_amdgcn_sched_barrier(0);      // keep the batches apart (registers)
     }
-    __syncthreads();
-    reduce_store(red, nw, partial, (size_t)pstride, w0, c);
+    const double sum = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    return fma(-(double)npad, last, sum);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -867,9 +848,10 @@ __device__ __forceinline__ double field_sum(const KConst& kc, const double* __re
     double lF[NF], V[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        lF[f] = r[RF(f, F_CA)];
-        V[f] = r[RF(f, F_V)];
+        lF[f] = uni(r[RF(f, F_CA)]);
+        V[f] = uni(r[RF(f, F_V)]);
     }
+    asm volatile("; LF_BEGIN node_general items=%0" ::"n"(NF));
     double s = 0.0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -883,6 +865,7 @@ __device__ __forceinline__ double field_sum(const KConst& kc, const double* __re
         const double lnfc = flog_half(fma(num, Z * d, 1.0), tab);
         s = fma(kc.om0_grid[f], fexp_t(fmax(lnfc * ((Z * sd) * Z), -750.0), tab), s);   // fc ** (1 / fc_decay)
     }
+    asm volatile("; LF_END node_general");
     return s;
 }
 
@@ -892,13 +875,15 @@ __device__ __forceinline__ double field_sum(const KConst& kc, const double* __re
 // fc ** 1.0 is fc itself: this form is the closer one.)
 template <int NF>
 __device__ __forceinline__ double field_sum_bright(const KConst& kc, const double* __restrict__ r, double alphaC, double a3) {
+    asm volatile("; LF_BEGIN node_bright items=%0" ::"n"(NF));
     double s = 0.0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const double num = fma(alphaC, a3, r[RF(f, F_CA)]);
+        const double num = fma(alphaC, a3, uni(r[RF(f, F_CA)]));
         const double w = fma(num, frsqrt(fma(num, num, 1.0)), 1.0);
         s = fma(0.5 * kc.om0_grid[f], w, s);
     }
+    asm volatile("; LF_END node_bright");
     return s;
 }
 
@@ -930,7 +915,7 @@ __device__ __forceinline__ double field_sum_nf(const KConst& kc, const double* _
 __device__ __forceinline__ double walker_vmin(const KConst& kc, const double* __restrict__ r) {
     double v = r[RF(0, F_V)];
     for (int f = 1; f < kc.nf; ++f) v = fmin(v, r[RF(f, F_V)]);
-    return v;
+    return uni(v);
 }
 
 template <int VARIANT, int TW>
@@ -954,8 +939,8 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
         if (wmode[(size_t)(w0 + w) * MAXF * WM] == MODE_SKIP) {
             val = 0.0;                                  // outside the prior: not evaluated
         } else if (VARIANT == LF_FREE) {
-            const double T = fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
-            const double alphaC = r[R_ALPHAC];
+            const double T = fexp_c(fma(uni(r[R_C1]), G - uni(r[R_LSTAR]), uni(r[R_C0])) - PG * uni(r[R_Q]), &tab);
+            const double alphaC = uni(r[R_ALPHAC]);
             const bool bright = kc.specialise && alphaC > 0.0 && a4min * walker_vmin(kc, r) > 37.5;
             if (kc.forms && tid == 0)
                 atomicAdd(kc.forms + (bright ? FORM_NODE_BRIGHT : FORM_NODE_GENERAL),
@@ -1093,12 +1078,9 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
                                                  int B, Tiling tl, int nchA, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
                                                  double* __restrict__ partB, int strideB, Rescue rs, GridC gc) {
-    constexpr bool TAB = VARIANT == LF_FREE && !CMP;     // the table-driven per-source form (srcsum_free)
     __shared__ MathTables tab;
-    __shared__ __attribute__((aligned(16))) double ttab[TAB ? sizeof(TermTables) / sizeof(double) : 2];
-    __shared__ double red[(TW > TWB ? TW : TWB) * BLOCK];
+    __shared__ __attribute__((aligned(16))) double red[(TW > TWB ? TW : TWB) * BLOCK];
     __shared__ double Tw[CMP ? GRIDC_MAX_S : 1];
-    TermTables& tt = *reinterpret_cast<TermTables*>(ttab);
     if (CMP) {
         // rescue workgroups have nothing to do unless lf_prepare listed a walker: leave before the table prologue
         const int first_resc = nblkB + nchA * (tl.ntiles + tl.ntiles_s);
@@ -1114,8 +1096,7 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
             return;
         }
     }
-    load_tables(&tab);
-    if (TAB && id >= nblkB) load_term_tables(&tt);
+    load_tables_256(&tab);
     __syncthreads();
     if (id < nblkB) {
         if (CMP && VARIANT == LF_FREE && gc.nb > 0) gridc_body<TWB>(kc, gc, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red, Tw);
@@ -1149,8 +1130,7 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
         w0 = tl.B1 + (wg - c * tl.ntiles_s) * tl.tws;
         nw = min(tl.tws, B - w0);
     }
-    if constexpr (TAB) srcsum_free<ST, TW>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, tt, red);
-    else srcsum_body<VARIANT, ST, TW, CMP>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
+    srcsum_body<VARIANT, ST, TW, CMP>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
 }
 
 // accept / reject walker k = half*halfW + w with the new lnprob `newlp`, and record it in the chain

@@ -129,13 +129,27 @@ struct TermTables {
     double g[G_N * 8];
     double h[H_N * 8];
 };
+// All loads are issued before the first LDS store (fixed trip counts, NT threads): the prologue of a workgroup pays ONE
+// round trip to L2 for the 27 KB, not one per loop iteration.
+template <int NT>
 __device__ __forceinline__ void load_term_tables(TermTables* tt) {
     double2* g2 = reinterpret_cast<double2*>(tt->g);
     double2* h2 = reinterpret_cast<double2*>(tt->h);
     const double2* G2 = reinterpret_cast<const double2*>(G_TABLE);
     const double2* H2 = reinterpret_cast<const double2*>(H_TABLE);
-    for (int i = threadIdx.x; i < G_N * 4; i += blockDim.x) g2[i] = G2[i];
-    for (int i = threadIdx.x; i < H_N * 4; i += blockDim.x) h2[i] = H2[i];
+    constexpr int NG = (G_N * 4 + NT - 1) / NT, NH = (H_N * 4 + NT - 1) / NT;
+    double2 vg[NG], vh[NH];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) vg[q] = G2[min(t + q * NT, G_N * 4 - 1)];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) vh[q] = H2[min(t + q * NT, H_N * 4 - 1)];
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+        if (t + q * NT < G_N * 4) g2[t + q * NT] = vg[q];
+#pragma unroll
+    for (int q = 0; q < NH; ++q)
+        if (t + q * NT < H_N * 4) h2[t + q * NT] = vh[q];
 }
 
 // degree-7 Horner from 8 coefficients held in registers
@@ -155,6 +169,14 @@ __device__ __forceinline__ void load_tables(MathTables* mt) {
         mt->logt[i] = make_double2(LOG_TABLE[2 * i], LOG_TABLE[2 * i + 1]);
         mt->expt[i] = EXP_TABLE[i];
     }
+}
+// the same for workgroups of exactly 256 threads: one straight-line pass
+__device__ __forceinline__ void load_tables_256(MathTables* mt) {
+    const int i = threadIdx.x;
+    const double2 l = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * i);
+    const double e = EXP_TABLE[i];
+    mt->logt[i] = l;
+    mt->expt[i] = e;
 }
 
 // 64-lane wavefront sum (no masks on CDNA: every lane takes part).

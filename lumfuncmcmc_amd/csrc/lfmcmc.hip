@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -17,6 +18,7 @@
 
 #include "lf_compress.h"
 #include "lf_kernels.h"
+#include "lf_free.h"
 
 namespace {
 
@@ -56,10 +58,17 @@ struct lf_ctx {
     std::vector<int64_t> field_ind;
     std::vector<double> h_x;            // FREE: host copy of the flux-sorted logf (chunk keys are derived from it)
     unsigned long long* d_forms = nullptr;   // census of the term forms (option "count_forms"), FORM_COUNT slots
+    int last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lf_last_launch
+    int* d_queue = nullptr;              // FREE: item counters of the persistent workgroups, [tiles][lf::QSTRIDE]
+    int cap_queue = 0;
+    int slots_free[3] = {0, 0, 0};       // workgroups of lf_free<2 / 4 / 8> the chip holds at once (0 = not asked yet)
+    int num_cu = 0;
     // device tables
     double *d_lum = nullptr, *d_a1 = nullptr, *d_P = nullptr, *d_U = nullptr;
     double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr, *d_a4min = nullptr;
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
+    std::map<int, ChunkTable> chunks_free;   // the persistent FREE kernel's (lf_free.h): 512 ST sources per chunk, lanes of ST
+    int64_t opt_persistent = 1;         // FREE: 1 = lf_free (persistent 512-thread workgroups) for catalogues that fill it
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     int64_t opt_taper = 0;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers (second pass over the catalogue)
@@ -120,7 +129,7 @@ int upload(lf_ctx* c, T** dst, const T* src, size_t n) {
 
 // hx: the flux-sorted logf of the REAL catalogue (FREE), or NULL (no keys: the chunks never take the table form)
 int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<int64_t>& field_ind, int ch,
-               ChunkTable** out, const double* hx = nullptr) {
+               ChunkTable** out, const double* hx = nullptr, int lane_w = 0) {
     auto it = tables.find(ch);
     if (it != tables.end()) {
         *out = &it->second;
@@ -177,7 +186,7 @@ int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<i
         keys[4 * i + 1] = lf::KEY_MAX;
         if (!hx) continue;
         const int64_t s = st[i], n = ln[i];
-        const int lane_w = ch / lf::BLOCK;
+        if (lane_w <= 0) continue;                // (a kernel that holds no lanes of flux-neighbours: no keys)
         double spread = 0.0;
         bool finite = true;
         for (int64_t j = 0; j < n; ++j) finite = finite && std::isfinite(hx[s + j]);
@@ -310,6 +319,14 @@ void launch_geo(lf_ctx* c, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int n
                 const lf::SrcArrays& sa, const lf::NodeArrays& na, int B, int nchA, int nchB,
                 const lf::Rescue& rs = lf::Rescue{}, const lf::GridC& gc = lf::GridC{}) {
     using namespace lf;
+    if (std::getenv("LF_DEBUG_OCC")) {
+        int nb = -1;
+        hipFuncAttributes fa{};
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, CMP>, BLOCK, 0);
+        hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, CMP>));
+        std::fprintf(stderr, "lf_main<%d,%d,%d,%d,%d>: %d workgroups per CU (occupancy API), %d VGPRs, %zu B LDS, grid %u\n", VARIANT,
+                     GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, (int)CMP, nb, fa.numRegs, fa.sharedSizeBytes, grid.x);
+    }
     hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, CMP>), grid, dim3(BLOCK), 0, s, c->kc, sa,
                        na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB, rs, gc);
 }
@@ -344,6 +361,91 @@ void launch_main(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int t
     }
 }
 
+// FREE variant, real catalogue, catalogues large enough to fill it: prepare -> lf_free (persistent 512-thread workgroups,
+// pieces A and B, lf_free.h) -> finalize
+template <int ST>
+void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa, const lf::NodeArrays& na, lf::FreeArgs fa, hipStream_t s) {
+    using namespace lf;
+    if (c->slots_free[slot] == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lf_free<ST, false>, PB, 0) != hipSuccess || nb < 1) nb = 1;
+        c->slots_free[slot] = nb * std::max(c->num_cu, 1);
+        if (std::getenv("LF_DEBUG_OCC")) {
+            hipFuncAttributes at{};
+            hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&lf_free<ST, false>));
+            std::fprintf(stderr, "lf_free<%d>: %d workgroups per CU (occupancy API), %d VGPRs, %zu B LDS\n", ST, nb, at.numRegs, at.sharedSizeBytes);
+        }
+    }
+    // groups of 8 workgroups (one per XCD under round-robin placement) per tile; no more than the chip holds at once,
+    // no more than there are items
+    const int64_t per_tile = ((int64_t)fa.nchA + fa.nchB + 7) / 8;
+    const int64_t g8 = std::max<int64_t>(1, std::min<int64_t>(c->slots_free[slot] / 8, (int64_t)ntiles * std::max<int64_t>(per_tile, 1)));
+    fa.tile_stride = (int)g8;
+    const dim3 grid((unsigned)(8 * g8));
+    const int info[8] = {ST, PTW, PTW, 2, (int)grid.x, fa.nchA, fa.nchB, B};
+    std::memcpy(c->last_launch, info, sizeof(info));
+    if (c->kc.forms) hipLaunchKernelGGL((lf_free<ST, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
+    else hipLaunchKernelGGL((lf_free<ST, false>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
+}
+
+int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB, hipStream_t s,
+                 const lf::StepArgs& sp, const lf::AcceptArgs& ap) {
+    using namespace lf;
+    const int ntiles = (B + PTW - 1) / PTW;
+    // sources per lane: 8 when that still leaves every workgroup a few items, else 4, else 2
+    const int slots = c->slots_free[2] ? c->slots_free[2] : 2 * std::max(c->num_cu, 1);
+    int st = 2, slot = 0;
+    for (int cand = 8, sl = 2; cand >= 2; cand /= 2, --sl) {
+        const int64_t chunks = (c->N + (int64_t)PB * cand - 1) / ((int64_t)PB * cand);
+        if (chunks * ntiles >= 2 * (int64_t)slots || cand == 2) {
+            st = cand;
+            slot = sl;
+            break;
+        }
+    }
+    ChunkTable* ct = nullptr;
+    int rc = get_chunks(c, c->chunks_free, c->field_ind, PB * st, &ct, c->h_x.data(), st);
+    if (rc != LF_OK) return rc;
+    const int nchA = ct->n;
+    const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + PB - 1) / PB;
+    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1));
+    if (rc != LF_OK) return rc;
+    if (ntiles * QSTRIDE > c->cap_queue) {
+        LF_HIP(c, hipDeviceSynchronize());
+        release(c->d_queue);
+        c->cap_queue = 0;
+        const int cap = std::max(2 * ntiles * QSTRIDE, 1024);
+        LF_HIP(c, hipMalloc((void**)&c->d_queue, (size_t)cap * sizeof(int)));
+        c->cap_queue = cap;
+    }
+    if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
+    c->last_stream = s;
+    c->any_enqueued = true;
+    {
+        Prof p(c, s, 0);
+        hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
+                           c->d_wstat, c->d_wmode, c->d_wbase, (int*)nullptr, c->d_queue, ntiles * QSTRIDE);
+    }
+    const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
+    const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
+    FreeArgs fa{B, ntiles, nchA, nchB, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB};
+    {
+        Prof p(c, s, 1);
+        if (nchA + nchB > 0) {
+            if (st == 8) launch_free<8>(c, slot, B, ntiles, sa, na, fa, s);
+            else if (st == 4) launch_free<4>(c, slot, B, ntiles, sa, na, fa, s);
+            else launch_free<2>(c, slot, B, ntiles, sa, na, fa, s);
+        }
+    }
+    {
+        Prof p(c, s, 3);
+        hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
+                           (const double*)nullptr, 0, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB, (int*)nullptr);
+    }
+    LF_HIP(c, hipGetLastError());
+    return LF_OK;
+}
+
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
             hipStream_t s, const lf::StepArgs* step = nullptr, const lf::AcceptArgs* accept = nullptr) {
     using namespace lf;
@@ -351,6 +453,11 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     AcceptArgs ap{};
     if (step) sp = *step;
     if (accept) ap = *accept;
+    // the persistent kernel takes the free variant's direct path whenever the catalogue can fill it and no launch
+    // geometry of lf_main was asked for explicitly
+    if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
+        !(c->opt_compress && c->cmp.built) && c->N >= 32768)
+        return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
     const bool cmp = c->opt_compress && c->cmp.built && c->kc.variant != LF_FIXCOMP;
     int gi = pick_geometry(c, B);
@@ -361,11 +468,10 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     }
     const Geo geo = GEOS[gi];
     ChunkTable *ct = nullptr, *ctd = nullptr;
-    const double* hx = c->h_x.empty() ? nullptr : c->h_x.data();
     int rc = cmp ? get_chunks(c, c->cmp.chunks, c->cmp.field_ind, geo.st * BLOCK, &ct)
-                 : get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ct, hx);
+                 : get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ct);
     if (rc != LF_OK) return rc;
-    if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd, hx)) != LF_OK) return rc;
+    if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd)) != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchD = cmp ? ctd->n : 0;
     // rescue workgroups leave at once unless a walker was flagged; still, each costs a dispatch slot: scale with B
@@ -382,9 +488,9 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 0);
         hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
-                           c->d_wstat, c->d_wmode, c->d_wbase, cmp ? c->d_slow : nullptr);
+                           c->d_wstat, c->d_wmode, c->d_wbase, cmp ? c->d_slow : nullptr, c->d_queue, 0);
     }
-    const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys};
+    const SrcArrays sd{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, c->d_queue};
     SrcArrays sa = sd;
     Rescue rs{};
     GridC gc{};
@@ -393,7 +499,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         gc = GridC{g.d_U, g.d_A4, g.d_row0, g.d_nrows, g.d_off, g.d_omega, g.d_L, g.d_PGL, g.nb, c->kc.S};
     }
     if (cmp) {
-        sa = SrcArrays{c->cmp.d_lum, c->cmp.d_a1, c->cmp.d_lum, c->cmp.d_U, c->cmp.d_W, ct->d_start, ct->d_len, ct->d_field, ct->d_keys};
+        sa = SrcArrays{c->cmp.d_lum, c->cmp.d_a1, c->cmp.d_lum, c->cmp.d_U, c->cmp.d_W, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
         rs.sd = sd;
         rs.sd.chunk_start = ctd->d_start;
         rs.sd.chunk_len = ctd->d_len;
@@ -441,6 +547,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         const int nblkB = nchB * ntilesB;
         // 1-D grid: B items, big A items, small A items, rescue workgroups
         dim3 grid((unsigned)(nblkB + nchA * (tl.ntiles + tl.ntiles_s) + nresc));
+        const int info[8] = {geo.st, geo.tw, geo.twb, cmp ? 1 : 0, (int)grid.x, nchA, nchB, B};
+        std::memcpy(c->last_launch, info, sizeof(info));
         if (grid.x > 0) {
             if (cmp) {
                 if (c->kc.variant == LF_FREE) launch_main_cmp<LF_FREE>(c, gi, grid, tl, ntilesB, twb, nblkB, s, sa, na, B, nchA, nchB, rs, gc);
@@ -591,6 +699,12 @@ void free_ctx(lf_ctx* c) {
         hipFree(kv.second.d_field);
         hipFree(kv.second.d_keys);
     }
+    for (auto& kv : c->chunks_free) {
+        hipFree(kv.second.d_start);
+        hipFree(kv.second.d_len);
+        hipFree(kv.second.d_field);
+        hipFree(kv.second.d_keys);
+    }
     free_cmp(c->cmp);
     if (c->d_partR) hipFree(c->d_partR);
     {
@@ -611,6 +725,7 @@ void free_ctx(lf_ctx* c) {
     if (c->d_wbase) hipFree(c->d_wbase);
     if (c->d_slow) hipFree(c->d_slow);
     if (c->d_forms) hipFree(c->d_forms);
+    if (c->d_queue) hipFree(c->d_queue);
     if (c->h_theta) hipHostFree(c->h_theta);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -630,6 +745,9 @@ int build(lf_ctx* c, const lf_desc* d) {
     kc.tables = 1;
     kc.key_x0 = 0.0;
     kc.forms = nullptr;
+#ifdef LF_STAMPS
+    kc.stamps = nullptr;
+#endif
     kc.nf = nf;
     kc.S = S;
     if (d->variant == LF_FREE) kc.ndim = 2 + (kc.fix_sch_al ? 0 : 1) + nf + 1;
@@ -825,6 +943,14 @@ int build(lf_ctx* c, const lf_desc* d) {
         }
         if ((rc = upload(c, &c->d_a4min, a4min.data(), a4min.size())) != LF_OK) return rc;
     }
+    {
+        hipDeviceProp_t prop;
+        LF_HIP(c, hipGetDeviceProperties(&prop, c->device));
+        c->num_cu = prop.multiProcessorCount;
+        LF_HIP(c, hipMalloc((void**)&c->d_queue, 1024 * sizeof(int)));
+        LF_HIP(c, hipMemset(c->d_queue, 0, 1024 * sizeof(int)));
+        c->cap_queue = 1024;
+    }
     LF_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const int mb = d->max_batch > 0 ? d->max_batch : 1024;
     return ensure_workspace(c, mb, 0, 0);
@@ -984,6 +1110,33 @@ int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
     return LF_OK;
 }
 
+#ifdef LF_STAMPS
+// diagnostic build only (tools/stamps.py): arm / read the per-workgroup time stamps of lf_main's source workgroups
+int lf_debug_stamps(lf_ctx* c, uint64_t* out, int64_t nblocks) {
+    if (!c) return LF_ERR_ARG;
+    LF_HIP(c, hipSetDevice(c->device));
+    LF_HIP(c, hipDeviceSynchronize());
+    if (!out) {                                   // arm for nblocks workgroups
+        if (c->kc.stamps) hipFree(c->kc.stamps);
+        c->kc.stamps = nullptr;
+        if (nblocks > 0) {
+            LF_HIP(c, hipMalloc((void**)&c->kc.stamps, (size_t)nblocks * 8 * sizeof(uint64_t)));
+            LF_HIP(c, hipMemset(c->kc.stamps, 0, (size_t)nblocks * 8 * sizeof(uint64_t)));
+        }
+        return LF_OK;
+    }
+    if (!c->kc.stamps) return LF_ERR_ARG;
+    LF_HIP(c, hipMemcpy(out, c->kc.stamps, (size_t)nblocks * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return LF_OK;
+}
+#endif
+
+int lf_last_launch(const lf_ctx* c, int32_t info[8]) {
+    if (!c || !info) return LF_ERR_ARG;
+    for (int i = 0; i < 8; ++i) info[i] = c->last_launch[i];
+    return LF_OK;
+}
+
 int lf_form_counts(lf_ctx* c, int64_t counts[8]) {
     if (!c || !counts) return LF_ERR_ARG;
     for (int i = 0; i < lf::FORM_COUNT; ++i) counts[i] = 0;
@@ -1027,6 +1180,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             LF_HIP(c, hipMemset(c->d_forms, 0, lf::FORM_COUNT * sizeof(unsigned long long)));
         }
         c->kc.forms = value != 0 ? c->d_forms : nullptr;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "persistent") == 0) {
+        c->opt_persistent = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "tables") == 0) {

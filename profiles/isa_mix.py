@@ -1,10 +1,17 @@
-"""Instruction mix of the per-term loops, from the compiler's assembly (hipcc -S): how many fp64
-VALU operations ONE (walker, source) term executes.  This is the count bench.py uses for the
-fp64-VALU roofline (FMA = 2 flops, every other fp64 VALU instruction = 1).
+"""Instruction mix of the per-term loops, from the compiler's assembly (hipcc -S): how many fp64 VALU operations ONE
+(walker, source) term or ONE (walker, node, field) term of the grid integral executes, per FORM of the term.
 
-    python profiles/isa_mix.py > profiles/r01_isa_mix.txt
+The kernels bracket each form's code with assembly comments (`; LF_BEGIN <name> items=N` ... `; LF_END <name>`,
+lf_kernels.h / lf_free.h): what the compiler laid out between them - for the table-driven form that includes the
+per-lane table lookup - divided by the N items it handles (sources per lane, fields per node, or 1 for a rolled loop)
+are the per-item figures.  bench.py reads them from the JSON this writes,
+so `roofline.achieved` (executed flops: FMA = 2, any other fp64 VALU instruction = 1) follows the binary.
+
+    python profiles/isa_mix.py                         -> profiles/isa_counts.json (also done by lumfuncmcmc_amd.build)
+    python profiles/isa_mix.py --report > profiles/r02_isa_mix.txt
 """
 import collections
+import json
 import os
 import re
 import subprocess
@@ -13,12 +20,16 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "lumfuncmcmc_amd", "csrc", "lfmcmc.hip")
+OUT = os.path.join(ROOT, "profiles", "isa_counts.json")
+NF_REPORTED = 5                   # the grid forms are instantiated for nf = 1..8: report the configLF case
+# issue cycles one wave spends (measured rates, profiles/r01_ubench.txt): fp64 VALU 4, v_rcp/v_rsq/v_sqrt_f64 16, 32-bit VALU ~2.5
+CYC_FP64, CYC_TRANS64, CYC_VALU32 = 4.0, 16.0, 2.5
 
 
-def assembly():
+def assembly(hipcc="/opt/rocm/bin/hipcc"):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "lf.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc",
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc",
                         "-Wno-unused-value", "-S", "--cuda-device-only", "-o", out, SRC], check=True,
                        stderr=subprocess.DEVNULL)
         return open(out).read()
@@ -29,16 +40,22 @@ def kernels(s):
         yield m.group(1), m.group(2).split("\n")
 
 
-def loops(lines):
-    labels = {}
-    for i, l in enumerate(lines):
-        m = re.match(r"^(\.LBB\d+_\d+):", l)
+def regions(lines):
+    """(form, items, instruction lines) of every `; LF_BEGIN form items=N` ... `; LF_END form` bracket, in layout order
+    (a bracket may span several basic blocks: everything the compiler laid out between the two markers)."""
+    cur = None
+    for l in lines:
+        m = re.search(r"; LF_BEGIN (\w+) items=(\d+)", l)
         if m:
-            labels[m.group(1)] = i
-    for i, l in enumerate(lines):
-        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i:
-            yield labels[m.group(1)], i
+            cur = (m.group(1), int(m.group(2)), [])
+            continue
+        m = re.search(r"; LF_END (\w+)", l)
+        if m and cur and cur[0] == m.group(1):
+            yield cur
+            cur = None
+            continue
+        if cur is not None:
+            cur[2].append(l)
 
 
 def mix(lines):
@@ -50,42 +67,70 @@ def mix(lines):
     return c
 
 
-def main():
-    s = assembly()
+def classify(c):
+    fp64 = {k: v for k, v in c.items() if k.startswith("v_") and "f64" in k}
+    trans = sum(v for k, v in fp64.items() if re.match(r"v_(rcp|rsq|sqrt)_f64", k))
+    fma = sum(v for k, v in fp64.items() if re.match(r"v_fma(c)?_f64", k))
+    cvt = sum(v for k, v in fp64.items() if k.startswith("v_cvt") or k.startswith("v_cmp") or k.startswith("v_ldexp") or k.startswith("v_mov"))
+    other = sum(fp64.values()) - fma - trans
+    valu32 = sum(v for k, v in c.items() if k.startswith("v_") and "f64" not in k)
+    lds = sum(v for k, v in c.items() if k.startswith("ds_read"))
+    return {"fma": fma, "fp64_other": other, "trans64": trans, "valu32": valu32, "lds_reads": lds,
+            "salu_smem": sum(v for k, v in c.items() if k.startswith("s_"))}
+
+
+def analyse(s):
+    """{kernel instantiation: {form: counts}} for every marked block."""
+    out = {}
     for name, lines in kernels(s):
-        m = re.search(r"lf_(?:srcsum|main)ILi(\d)ELi(\d+)ELi(\d+)", name)
-        if not m:
+        m = re.search(r"lf_mainILi(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)", name)
+        mf = re.search(r"lf_freeILi(\d+)ELb0", name)          # the persistent FREE kernel, product instantiation
+        if mf:
+            st = int(mf.group(1))
+            key = "lf_free<%d>" % st
+        elif m:
+            variant, st, tw, twb, cmp_ = (int(x) for x in m.groups())
+            key = "lf_main<%d,%d,%d,%d,%s>" % (variant, st, tw, twb, "true" if cmp_ else "false")
+        else:
             continue
-        variant, st = int(m.group(1)), int(m.group(2))
-        for a, b in loops(lines):
-            c = mix(lines[a:b + 1])
-            fp64 = {k: v for k, v in c.items() if k.startswith("v_") and "f64" in k}
-            if variant == 0 and c.get("v_rsq_f64_e32", 0) >= 30 and not c.get("v_div_scale_f64", 0):
-                # the walker loop of the grid integral (piece B): the switch over nf = 1..8 is unrolled inline, i.e. the
-                # loop body holds 36 field terms (exp, rsqrt, log, exp each) and 8 copies of the per-node tail
-                fma = c["v_fma_f64"] + c["v_fmac_f64_e32"]
-                other = sum(fp64.values()) - fma
-                print("lf_main<variant 0, ST %d>  grid walker loop, all nf = 1..8 cases inline (36 field terms + 8 per-node tails): "
-                      "fp64 fma %d, other fp64 %d -> %d executed flops = 36 x %.1f + 8 x 23 (bench.py counts 70 per node-field + 23 per node)"
-                      % (st, fma, other, 2 * fma + other, (2 * fma + other - 8 * 23) / 36.0))
+        for form, items, body in regions(lines):
+            if form.startswith("node_") and items != NF_REPORTED:
                 continue
-            careful = c.get("v_div_scale_f64", 0) or (c.get("v_cndmask_b32_e64", 0) + c.get("v_cndmask_b32_e32", 0) >= st)
-            if b - a < 20 * st or careful:           # skip small loops and the careful (checked) path
-                continue
-            fma = c["v_fma_f64"] + c["v_fmac_f64_e32"]
-            other = sum(fp64.values()) - fma
-            ints = sum(v for k, v in c.items() if k.startswith("v_") and "f64" not in k)
-            lds = sum(v for k, v in c.items() if k.startswith("ds_read"))
-            if variant == 0 and c.get("v_rsq_f64_e32", 0) == 2 * st:
-                print("   (next loop: the walker loop of the free variant holds BOTH forms of the term - the general one, "
-                      "54 flops / 174 cycles, and term_free_noexp: the rest)")
-            print("lf_main<variant %d, ST %d>  loop of %d lines, per item (term or grid node-field):" % (variant, st, b - a))
-            print("   fp64 fma %.2f   other fp64 VALU %.2f   32-bit VALU %.2f   LDS reads %.2f" % (fma / st, other / st, ints / st, lds / st))
-            print("   executed fp64 flops/term (fma = 2, other = 1): %.1f" % ((2 * fma + other) / st))
-            print("   issue cycles/term-wave (fp64 4, rcp/rsq 16, 32-bit ~2.5): %.0f" % (
-                (4 * (fma + other - c.get("v_rcp_f64_e32", 0) - c.get("v_rsq_f64_e32", 0)) + 16 * (c.get("v_rcp_f64_e32", 0) + c.get("v_rsq_f64_e32", 0)) + 2.5 * ints) / st))
-            print("   mix:", ", ".join("%s %d" % kv for kv in c.most_common(24)))
+            cl = classify(mix(body))
+            cl["items"] = items
+            cl["flops_per_item"] = (2.0 * cl["fma"] + cl["fp64_other"] + cl["trans64"]) / items
+            cl["cycles_per_item"] = (CYC_FP64 * (cl["fma"] + cl["fp64_other"]) + CYC_TRANS64 * cl["trans64"] +
+                                     CYC_VALU32 * cl["valu32"]) / items
+            cl["instructions_in_region"] = sum(mix(body).values())
+            if form not in out.setdefault(key, {}):        # (a form inlined twice: the first copy)
+                out[key][form] = cl
+    return out
+
+
+def write_json(path=OUT, hipcc="/opt/rocm/bin/hipcc"):
+    a = analyse(assembly(hipcc))
+    doc = {"source": "profiles/isa_mix.py over lumfuncmcmc_amd/csrc/lfmcmc.hip (hipcc -O3 --offload-arch=gfx950 -S)",
+           "units": "flops: FMA = 2, other fp64 VALU = 1; cycles: issue cycles of one wave (fp64 4, rcp/rsq 16, 32-bit VALU 2.5)",
+           "nf_of_grid_forms": NF_REPORTED, "kernels": a}
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+        f.write("\n")
+    return doc
+
+
+def report(doc):
+    for k in sorted(doc["kernels"]):
+        print(k)
+        for form, c in sorted(doc["kernels"][k].items()):
+            print("   %-20s per item: %5.1f executed flops, %5.1f issue cycles | region of %d instructions for %d items: "
+                  "fp64 fma %d, other fp64 %d, rcp/rsq %d, 32-bit VALU %d, LDS reads %d, scalar %d" % (
+                      form, c["flops_per_item"], c["cycles_per_item"], c["instructions_in_region"], c["items"], c["fma"],
+                      c["fp64_other"], c["trans64"], c["valu32"], c["lds_reads"], c["salu_smem"]))
 
 
 if __name__ == "__main__":
-    main()
+    d = write_json()
+    if "--report" in sys.argv:
+        report(d)
+    else:
+        print(OUT)
