@@ -142,6 +142,10 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * g(num) = ln fc and h(y) = 1 / (1 - e^(-10^y)) (piecewise degree-7 polynomials, relative error <= 8e-15 over their
  * whole domain, lf_tables.h), for (walker, chunk) pairs whose fluxes lie inside the tables and whose lanes of
  * flux-neighbours are narrower than the tables' margins; 0 = always the general form (A/B runs).
+ * "persistent": 1 (default) runs the free variant's direct path in lf_free - persistent 512-thread workgroups that
+ * hold the g / h tables in LDS, serve one tile of 8 walkers and pull catalogue and grid chunks from per-XCD queues -
+ * whenever the catalogue gives every workgroup several items (about N x rows >= 1e8); 0 = always lf_main; 2 = lf_free
+ * whenever N >= 32768 (tests).  "free_st": sources per lane of lf_free, 0 (auto = 8), 2, 4 or 8 (tuning runs).
  * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
  * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
  * Two keys change what is computed, for SOURCE-SHARDED ranks whose lnprob values are summed (all-reduce): "skip_grid" = 1

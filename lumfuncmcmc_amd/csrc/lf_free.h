@@ -28,7 +28,7 @@ constexpr int PTW = 8;       // walkers per tile
 constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalogue queues of XCD 0..7
 
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
-// (eight columns per lane, stride 64) and runs one 64-lane tree.  Fixed order.
+// (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
 __device__ __forceinline__ void reduce_store512(const double* __restrict__ red, int nw, double* __restrict__ out,
                                                 size_t stride, int w0, int chunk) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -36,8 +36,8 @@ __device__ __forceinline__ void reduce_store512(const double* __restrict__ red, 
         const double* row = red + w * PB + lane;
         double s0 = (row[0] + row[64]) + (row[128] + row[192]);
         double s1 = (row[256] + row[320]) + (row[384] + row[448]);
-        const double s = wave_sum(s0 + s1);
-        if (lane == 0) out[(size_t)(w0 + w) * stride + chunk] = s;
+        const double s = wave_sum_dpp(s0 + s1);
+        if (lane == 63) out[(size_t)(w0 + w) * stride + chunk] = s;
     }
 }
 
@@ -98,6 +98,23 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             }
             return -1;
         };
+        // The claim of the item after the current one is split in two so that nobody waits for the atomic's round trip
+        // (2.3k cycles, tools/stamps.py): thread 0 takes a TICKET of the queue it expects to serve it - the grid queue
+        // until that has run dry once, then its XCD's catalogue queue - right after the current item's loads are
+        // issued, and turns it into an item (or falls back to the full search) only at the end of the walker loop.
+        bool grid_dry = fa.skip_grid || fa.nchB <= 0;      // (thread 0's view)
+        int ticket = 0;
+        auto take_ticket = [&]() { ticket = atomicAdd(grid_dry ? q + 1 + myq : q, 1); };
+        auto redeem = [&]() -> int {
+            if (!grid_dry) {
+                if (ticket < fa.nchB) return ticket;
+                grid_dry = true;
+                return grab();
+            }
+            const int lo = (int)(((long long)myq * fa.nchA) >> 3), hi = (int)(((long long)(myq + 1) * fa.nchA) >> 3);
+            if (ticket < hi - lo) return fa.nchB + lo + ticket;
+            return grab();                        // our queue is empty: steal (the grid queue and ours just hand out misses)
+        };
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
         if (tid == 0) sitem[0] = grab();
         // the tile's walker constants, all fields (64 B per (walker, field)), once
@@ -137,16 +154,21 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 
 #pragma unroll 1
         while (item >= 0) {
-            __syncthreads();                      // [D] the previous item's reduction has read `red`
-            if (tid == 0) sitem[0] = grab();
+            __syncthreads();                      // [D] the previous item's reduction has read `red` (and sitem)
             if (item >= fa.nchB) {
                 // ================= catalogue chunk: piece A =================
                 const int c = item - fa.nchB;
                 const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
                 const int kfirst = sa.chunk_keys[4 * c], klast = sa.chunk_keys[4 * c + 1], kamax = sa.chunk_keys[4 * c + 2];
                 // switch in: the chunk's sources, coalesced (instruction k of a wave reads 512 contiguous bytes), via LDS
+                {
+                    double xs[ST];
 #pragma unroll
-                for (int k = 0; k < ST; ++k) red[k * PB + tid] = sa.a1[(size_t)s0 + min(k * PB + tid, n - 1)];
+                    for (int k = 0; k < ST; ++k) xs[k] = sa.a1[(size_t)s0 + min(k * PB + tid, n - 1)];
+                    if (tid == 0) take_ticket();  // behind the loads: waiting for them does not wait for it
+#pragma unroll
+                    for (int k = 0; k < ST; ++k) red[k * PB + tid] = xs[k];
+                }
                 __syncthreads();                  // [A]
                 double x[ST];
                 {
@@ -158,15 +180,16 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                         x[2 * k + 1] = a.y;
                     }
                 }
-                const int next = sitem[0];
                 __syncthreads();                  // [B] the staging area becomes the reduction buffer again
                 // slots past the end of the chunk hold copies of its last source
                 const int npad = ST - min(max(n - tid * ST, 0), ST);
                 // ---- pass 1: the walkers whose (walker, chunk) pair takes the table-driven form (the bulk)
                 int rest = 0;                     // bit w: walker w needs pass 2 (wave-uniform)
+                WalkerK pn = fetch(0, fld);       // the next walker's constants are read while this one's terms run
 #pragma unroll 1
                 for (int w = 0; w < nw; ++w) {
-                    const WalkerK p = fetch(w, fld);
+                    const WalkerK p = pn;
+                    pn = fetch(min(w + 1, nw - 1), fld);
                     double acc = 0.0;
                     if (p.mode < MODE_SKIP && p.mode != MODE_SLOW && kc.tables && kfirst >= p.klo && klast <= p.khi && p.kac <= kamax) {
                         TabCoef C;
@@ -242,9 +265,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                         red[w * PB + tid] = acc;
                     }
                 }
+                if (tid == 0) sitem[0] = redeem();
                 __syncthreads();                  // [C]
                 reduce_store512(red, nw, fa.partA, (size_t)fa.nchA, w0, c);
-                item = next;
+                item = sitem[0];
             } else {
                 // ================= node chunk: piece B =================
                 const int c = item;
@@ -252,8 +276,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int g = min(c * PB + tid, na.nnodes - 1);
                 const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0, a3 = na.a3[g], a4 = na.a4[g];
                 const double a4min = fmin(na.a4min[2 * c], na.a4min[min(2 * c + 1, (na.nnodes + BLOCK - 1) / BLOCK - 1)]);   // wave-uniform
-                __syncthreads();                  // [A] (sitem)
-                const int next = sitem[0];
+                if (tid == 0) take_ticket();
                 const int nodes_here = min(PB, na.nnodes - c * PB);
 #pragma unroll 1
                 for (int w = 0; w < nw; ++w) {
@@ -275,9 +298,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     }
                     red[w * PB + tid] = val;
                 }
+                if (tid == 0) sitem[0] = redeem();
                 __syncthreads();                  // [C]
                 reduce_store512(red, nw, fa.partB, (size_t)fa.nchB, w0, c);
-                item = next;
+                item = sitem[0];
             }
 #ifdef LF_STAMPS
             ++nitems_done;

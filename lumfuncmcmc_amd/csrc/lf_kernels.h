@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
                     // rounded): num = alpha_C x + cA inside the g table, y = x + cY inside the h table, both with
                     // room for the margins; and from where on h = 1 (f / f_tau > 37.5: decay factor exactly 1.0).
                     int klo = KEY_MAX, khi = -1, kne = KEY_MAX, kac = KEY_MAX;
-                    if (alphaC > 0.0 && alphaC < 1.0e4) {
+                    if (nqueue > 0 && alphaC > 0.0 && alphaC < 1.0e4) {      // (only lf_free reads the keys)
                         const double xlo = fmax((G_NUM_LO + 2.0 * G_MARGIN - cA) / alphaC, H_LO + 2.0 * H_MARGIN - cY);
                         const double xhi = (G_NUM_HI - 2.0 * G_MARGIN - cA) / alphaC;
                         const double xne = 1.5740312677277188 - cY;            // log10(37.5)

@@ -179,6 +179,26 @@ __device__ __forceinline__ void load_tables_256(MathTables* mt) {
     mt->expt[i] = e;
 }
 
+// 64-lane wavefront sum on the DPP network (no LDS crossbar): row_shr 1, 2, 4, 8 inside the 16-lane rows, then
+// row_bcast15 / row_bcast31 across them; the total arrives in lane 63.  The __shfl_down tree of wave_sum goes through
+// ds_bpermute - twelve LDS round trips per double - and took 3.9k cycles at the end of every workgroup-wide item.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    // lanes that receive nothing (bound_ctrl off, old = 0) add 0: each step is a valid partial sum in the upper lanes
+    v = dpp_shift_add<0x111, 0xf>(v);     // row_shr:1
+    v = dpp_shift_add<0x112, 0xf>(v);     // row_shr:2
+    v = dpp_shift_add<0x114, 0xf>(v);     // row_shr:4
+    v = dpp_shift_add<0x118, 0xf>(v);     // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_shift_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_shift_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3  -> lane 63 holds the total
+    return v;
+}
+
 // 64-lane wavefront sum (no masks on CDNA: every lane takes part).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -69,6 +69,7 @@ struct lf_ctx {
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     std::map<int, ChunkTable> chunks_free;   // the persistent FREE kernel's (lf_free.h): 512 ST sources per chunk, lanes of ST
     int64_t opt_persistent = 1;         // FREE: 1 = lf_free (persistent 512-thread workgroups) for catalogues that fill it
+    int64_t opt_free_st = 0;            // lf_free: sources per lane, 0 = chosen from N and B, else 2 / 4 / 8 (tuning runs)
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     int64_t opt_taper = 0;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers (second pass over the catalogue)
@@ -397,7 +398,7 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     int st = 2, slot = 0;
     for (int cand = 8, sl = 2; cand >= 2; cand /= 2, --sl) {
         const int64_t chunks = (c->N + (int64_t)PB * cand - 1) / ((int64_t)PB * cand);
-        if (chunks * ntiles >= 2 * (int64_t)slots || cand == 2) {
+        if (c->opt_free_st ? cand == c->opt_free_st : (cand == 8 || chunks * ntiles >= 2 * (int64_t)slots || cand == 2)) {
             st = cand;
             slot = sl;
             break;
@@ -456,8 +457,16 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     // the persistent kernel takes the free variant's direct path whenever the catalogue can fill it and no launch
     // geometry of lf_main was asked for explicitly
     if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
-        !(c->opt_compress && c->cmp.built) && c->N >= 32768)
-        return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
+        !(c->opt_compress && c->cmp.built) && c->N >= 32768) {
+        // Measured crossover (B = 128: lf_main 41 / 66 / 167 us at N = 1e5 / 3e5 / 1e6, lf_free 55 / 96 / 145): the
+        // persistent kernel wins once every one of its ~512 workgroups gets about six items or more (items = 4096-source
+        // chunks and 512-node chunks per tile of 8 walkers); below that its coarse items cost more than its tables save.
+        // opt_persistent = 2 or an explicit free_st force it (tests, tuning runs).
+        const int64_t ntiles = (B + PTW - 1) / PTW;
+        const int64_t items = ((c->N + 8 * (int64_t)PB - 1) / (8 * (int64_t)PB) + (c->nnodes + PB - 1) / PB) * ntiles;
+        if (items >= 6 * 2 * (int64_t)std::max(c->num_cu, 1) || c->opt_persistent == 2 || c->opt_free_st)
+            return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
+    }
     // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
     const bool cmp = c->opt_compress && c->cmp.built && c->kc.variant != LF_FIXCOMP;
     int gi = pick_geometry(c, B);
@@ -1182,8 +1191,16 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
         c->kc.forms = value != 0 ? c->d_forms : nullptr;
         return LF_OK;
     }
+    if (std::strcmp(key, "free_st") == 0) {
+        if (value != 0 && value != 2 && value != 4 && value != 8) {
+            c->err = "free_st must be 0 (auto), 2, 4 or 8";
+            return LF_ERR_ARG;
+        }
+        c->opt_free_st = value;
+        return LF_OK;
+    }
     if (std::strcmp(key, "persistent") == 0) {
-        c->opt_persistent = value != 0;
+        c->opt_persistent = value < 0 ? 0 : (value > 2 ? 2 : value);
         return LF_OK;
     }
     if (std::strcmp(key, "tables") == 0) {

@@ -23,6 +23,7 @@ def test_table_form_equals_general_form(n, wide):
     from lumfuncmcmc_amd.capi import LFContext
     inp = make_inputs("free", n, seed=91)
     ctx = LFContext(inp)
+    ctx.set_option("persistent", 2)                # lf_free whatever the size (auto: only when it pays)
     th = _rows(96, 92, wide)
     th[5, 0] = 40.2                                # underflow zone: -inf
     th[6, 1] = 6.0                                 # outside the prior
@@ -52,10 +53,37 @@ def test_table_form_equals_general_form(n, wide):
     np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=5e-14)
 
 
+@pytest.mark.parametrize("st", [2, 4, 8])
+def test_persistent_kernel_equals_lf_main(st):
+    """lf_free (persistent workgroups, every sources-per-lane instantiation) against lf_main on the same context."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", 150001, seed=97)
+    ctx = LFContext(inp)
+    th = _rows(50, 98, wide=True)
+    th[7, 0] = 40.2
+    th[9, 8] = 0.5
+    ctx.set_option("persistent", 0)
+    a0, b0 = ctx.lnprob_pieces(th)
+    lp0 = ctx.lnprob_batch(th)
+    assert ctx.last_launch()["kernel"] == "lf_main"
+    ctx.set_option("persistent", 2)
+    ctx.set_option("free_st", st)
+    a1, b1 = ctx.lnprob_pieces(th)
+    lp1 = ctx.lnprob_batch(th)
+    assert ctx.last_launch()["kernel"] == "lf_free<%d>" % st
+    ctx.close()
+    assert np.array_equal(np.isnan(a1), np.isnan(a0)) and np.array_equal(np.isinf(lp1), np.isinf(lp0))
+    fin = np.isfinite(lp0)
+    np.testing.assert_allclose(a1[fin], a0[fin], rtol=5e-14)
+    np.testing.assert_allclose(b1[fin], b0[fin], rtol=1e-14)
+    np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=5e-14)
+
+
 def test_table_form_against_the_oracle():
     from lumfuncmcmc_amd.capi import LFContext
     inp = make_inputs("free", 300007, seed=93)
     ctx = LFContext(inp)
+    ctx.set_option("persistent", 2)
     th = _rows(6, 94)
     ctx.set_option("count_forms", 1)
     a, b = ctx.lnprob_pieces(th)
@@ -73,6 +101,7 @@ def test_census_adds_up():
     from lumfuncmcmc_amd.capi import LFContext
     inp = make_inputs("free", 250000, seed=95)
     ctx = LFContext(inp)
+    ctx.set_option("persistent", 2)
     th = _rows(40, 96, wide=True)
     th[3, 8] = 9.0                                 # outside the prior: its terms are counted as skipped
     ctx.set_option("count_forms", 1)
