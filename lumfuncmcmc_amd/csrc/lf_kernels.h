@@ -492,7 +492,7 @@ __device__ __forceinline__ double lnT_zevol(const WZ& w, double lum, double z, d
 // ----------------------------------------------------------------------------------------------
 // block reduction: red[nw][256] (LDS) -> out[(w0 + w) * stride + chunk], nw <= 16.
 // All walkers at once: thread t = (walker t >> 4, column group t & 15) adds its 16 columns (stride 16: consecutive
-// lanes read consecutive doubles), then the 16 lanes of a walker combine with four xor-shuffles inside their
+// lanes read consecutive doubles), then the 16 lanes of a walker combine with four DPP row shifts inside their
 // 16-lane row.  Fixed order: the bits depend on the launch geometry only.  (The first version gave each wave four
 // walkers in turn, a 64-lane shuffle tree each: 3.3k cycles of dependent latency at the end of every workgroup,
 // 8 % of its lifetime, measured with tools/stamps.py.)
@@ -513,11 +513,12 @@ __device__ __forceinline__ void reduce_store(const double* __restrict__ red, int
             s3 += row[16 * (i + 3)];
         }
         double sum = (s0 + s1) + (s2 + s3);
-        sum += __shfl_xor(sum, 8, 16);
-        sum += __shfl_xor(sum, 4, 16);
-        sum += __shfl_xor(sum, 2, 16);
-        sum += __shfl_xor(sum, 1, 16);
-        if (j == 0 && w < nw) out[(size_t)(widx ? widx[w] : w0 + w) * stride + chunk] = sum;
+        // the 16 lanes of a walker are one DPP row: row_shr 1, 2, 4, 8 leave the row's sum in its lane 15
+        sum = dpp_shift_add<0x111, 0xf>(sum);
+        sum = dpp_shift_add<0x112, 0xf>(sum);
+        sum = dpp_shift_add<0x114, 0xf>(sum);
+        sum = dpp_shift_add<0x118, 0xf>(sum);
+        if (j == 15 && w < nw) out[(size_t)(widx ? widx[w] : w0 + w) * stride + chunk] = sum;
     }
 }
 
@@ -1214,9 +1215,9 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
     for (; c < nchA; c += 64) a += pa[c];
     a = (a + a1) + (a2 + a3);
     for (c = lane; c < nchB; c += 64) b += pb[c];
-    a = wave_sum(a);
-    b = wave_sum(b);
-    if (lane == 0) {
+    a = wave_sum_dpp(a);                            // totals in lane 63
+    b = wave_sum_dpp(b);
+    if (lane == 63) {
         const int st = wstat[w];
         const bool ok = (st & STAT_PRIOR_OK) != 0;
         a += wbase[w];
@@ -1226,9 +1227,10 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
         if (out) out[w] = r;
         if (outA) outA[w] = ok ? a : __builtin_nan("");
         if (outB) outB[w] = ok ? b : __builtin_nan("");
-        a = r;                                   // lane 0 keeps the new lnprob for the accept step
+        a = r;                                   // lane 63 keeps the new lnprob for the accept step
     }
-    if (ap.enabled) accept_walker(ap, w, __shfl(a, 0, 64), lane);
+    if (ap.enabled)
+        accept_walker(ap, w, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63)), lane);
 }
 
 }  // namespace lf
