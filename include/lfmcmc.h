@@ -216,6 +216,19 @@ int64_t lf_compress_grid(const double *params, int S, const double *L, const dou
                          const double *Dk, double *u, int32_t *row0, int32_t *nrows, int32_t *off, double *omega,
                          int64_t cap_bins, int64_t cap_omega, double *bound);
 
+/* 1/Veff estimator on the device (post-fit diagnostic, no context needed).  Replaces the per-source loop of
+ * LumFuncMCMC.VeffLF (lumfuncmcmc.py:515-525: V.lumfunc, one scipy.quad per source, VmaxLumFunc.py:235-257) and the
+ * nboot x nbins masked sums of V.getBootErrLog (VmaxLumFunc.py:304-378).  All arrays host, length n unless noted.
+ *   phi[i] = 1 / (pref0 * fleming(flux[i], flim[i], alpha, fcmin) * (vol ? vol[i] : vol_all)),  0 where the volume is <= 0
+ *   (pref0 = sum(Omega_0) / sqarcsec; fcmin <= 0 = the unmodified Fleming curve);
+ *   sums[(nboot + 1) * nbin]: row 0 = sum of phi per luminosity bin (bin_of[i] in [0, nbin), anything else = no bin),
+ *   rows 1..nboot = the same over bootstrap resamples of the catalogue: indices from boot_idx[nboot * n] when given
+ *   (a caller replaying a seeded host stream), else drawn on the device (Philox4x32-10 keyed by seed).
+ * nbin = 0 skips the binning (bin_of, sums may be NULL).  nbin <= 1024.  Synchronous. */
+int lf_veff(int device, int64_t n, const double *flux, const double *flim, const double *vol, double vol_all, double pref0,
+            double alpha, double fcmin, const int32_t *bin_of, int32_t nbin, int32_t nboot, const int64_t *boot_idx, uint64_t seed,
+            double *phi, double *sums);
+
 /* Last error message of this context (or of lf_create when ctx == NULL).  Never NULL. */
 const char *lf_last_error(const lf_ctx *ctx);
 

@@ -43,7 +43,7 @@ EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_ba
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
-           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_form_counts", "lf_last_launch")
+           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_form_counts", "lf_last_launch", "lf_veff")
 
 _lib = None
 
@@ -94,6 +94,10 @@ def load():
     lib.lf_form_counts.argtypes = [ctypes.c_void_p, _c_int64_p]
     lib.lf_last_launch.restype = ctypes.c_int
     lib.lf_last_launch.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+    lib.lf_veff.restype = ctypes.c_int
+    lib.lf_veff.argtypes = [ctypes.c_int, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_double,
+                            ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32,
+                            _c_int64_p, ctypes.c_uint64, _c_double_p, _c_double_p]
     lib.lf_last_error.restype = ctypes.c_char_p
     lib.lf_last_error.argtypes = [ctypes.c_void_p]
     lib.lf_sampler_create.restype = ctypes.c_void_p
@@ -165,6 +169,29 @@ def compress_grid(params, L, wL, ck, Dk):
     nom = int(off[nb - 1] + nrows[nb - 1] * 16)
     return {"u": u[:nb * 16].reshape(nb, 16).copy(), "row0": row0[:nb].copy(), "nrows": nrows[:nb].copy(),
             "off": off[:nb].copy(), "omega": omega[:nom].copy(), "bound": float(bound[0])}
+
+
+def veff_device(flux, flim, vol, pref0, alpha, fcmin, bin_of=None, nbin=0, nboot=0, boot_idx=None, seed=0, device=0):
+    """lf_veff (include/lfmcmc.h): 1/Veff weights, and optionally their binned sums over the catalogue and over nboot
+    bootstrap resamples, on the GPU.  vol: scalar or per-source array.  Returns (phi[n], sums[(nboot + 1), nbin] or None)."""
+    lib = load()
+    flux, flim = _f64(flux), _f64(flim)
+    n = flux.size
+    volarr = None if np.ndim(vol) == 0 else _f64(vol)
+    phi = np.empty(n)
+    sums = np.zeros((nboot + 1, nbin)) if nbin > 0 else None
+    b32 = None if bin_of is None else np.ascontiguousarray(bin_of, dtype=np.int32)
+    bidx = None if boot_idx is None else np.ascontiguousarray(boot_idx, dtype=np.int64)
+    if bidx is not None and bidx.shape != (nboot, n):
+        raise ValueError("boot_idx must be (nboot, n)")
+    rc = lib.lf_veff(int(device), n, _ptr(flux), _ptr(flim), _ptr(volarr), float(vol) if volarr is None else 0.0, float(pref0),
+                     float(alpha), float(fcmin) if fcmin else 0.0,
+                     None if b32 is None else b32.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(nbin), int(nboot),
+                     None if bidx is None else bidx.ctypes.data_as(_c_int64_p), ctypes.c_uint64(int(seed)), _ptr(phi),
+                     None if sums is None else _ptr(sums))
+    if rc != LF_OK:
+        raise LFError("lf_veff failed (%d)" % rc)
+    return phi, sums
 
 
 def _ptr(a):

@@ -1233,4 +1233,58 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
         accept_walker(ap, w, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63)), lane);
 }
 
+// ----------------------------------------------------------------------------------------------
+// 1/Veff estimator (post-fit diagnostic): LumFuncMCMC.VeffLF, lumfuncmcmc.py:515-525 ->
+// V.lumfunc (VmaxLumFunc.py:235-257) and V.getBootErrLog (:304-378).
+//   veff_weights: phi_i = 1 / (sum(Omega_0)/sqarcsec * fleming(F_i, Flim_i, alpha, fcmin) * vol_i)   (device-library math)
+//   veff_bins:    for resample k (blockIdx.y) the binned sums sum_{j} phi[idx_kj] [bin(idx_kj) == b]; k = 0 is the
+//                 catalogue itself, k >= 1 draws idx_kj = floor(u N) from Philox4x32-10 (counter = (j, k), key = seed),
+//                 or reads it from `boot_idx` when the caller supplies the indices (tests replay the reference's seeded
+//                 numpy stream through the same kernel).  LDS bins per workgroup, one global atomic per bin.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void veff_weights(const double* __restrict__ flux, const double* __restrict__ flim, const double* __restrict__ vol,
+                                                    double vol_all, double pref0, double alpha, double fc_ratio, int use_fcmin,
+                                                    long long n, double* __restrict__ phi) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double f = flux[i], fl = flim[i];
+    const double num = alpha * log10(f / fl);                               // VmaxLumFunc.py:118-120
+    double fc = 0.5 * (1.0 + num / sqrt(1.0 + num * num));
+    if (use_fcmin) {
+        const double ftau = fl * exp10(-sqrt(fc_ratio / (alpha * alpha)));   // :164-167
+        fc = pow(fc, 1.0 / (1.0 - exp(-f / ftau)));                          // :141, :125
+    }
+    const double v = vol ? vol[i] : vol_all;
+    phi[i] = v > 0.0 ? 1.0 / (pref0 * fc * v) : 0.0;
+}
+
+constexpr int VEFF_MAXBIN = 1024;
+__global__ __launch_bounds__(256) void veff_bins(const double* __restrict__ phi, const int* __restrict__ bin_of, long long n, int nbin,
+                                                 const long long* __restrict__ boot_idx, unsigned long long seed,
+                                                 double* __restrict__ sums /* [nres][nbin] */) {
+    __shared__ double lb[VEFF_MAXBIN];
+    const int k = blockIdx.y;
+    for (int b = threadIdx.x; b < nbin; b += blockDim.x) lb[b] = 0.0;
+    __syncthreads();
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long long)gridDim.x * blockDim.x) {
+        long long idx = j;
+        if (k > 0) {
+            if (boot_idx) {
+                idx = boot_idx[(size_t)(k - 1) * (size_t)n + (size_t)j];
+            } else {
+                unsigned int r[4];
+                philox4x32((unsigned int)j, (unsigned int)((unsigned long long)j >> 32), (unsigned int)k, 0x5eedu, (unsigned int)seed,
+                           (unsigned int)(seed >> 32), r);
+                idx = (long long)(u53(r[0], r[1]) * (double)n);
+                if (idx >= n) idx = n - 1;
+            }
+        }
+        const int b = bin_of[idx];
+        if (b >= 0 && b < nbin) atomicAdd(&lb[b], phi[idx]);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbin; b += blockDim.x)
+        if (lb[b] != 0.0) atomicAdd(&sums[(size_t)k * nbin + b], lb[b]);
+}
+
 }  // namespace lf

@@ -1140,6 +1140,58 @@ int lf_debug_stamps(lf_ctx* c, uint64_t* out, int64_t nblocks) {
 }
 #endif
 
+int lf_veff(int device, int64_t n, const double* flux, const double* flim, const double* vol, double vol_all, double pref0,
+            double alpha, double fcmin, const int32_t* bin_of, int32_t nbin, int32_t nboot, const int64_t* boot_idx, uint64_t seed,
+            double* phi, double* sums) {
+    if (n <= 0 || !flux || !flim || !phi || pref0 <= 0.0 || nbin < 0 || nbin > lf::VEFF_MAXBIN || nboot < 0 || (nbin > 0 && (!bin_of || !sums)))
+        return LF_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return LF_ERR_NODEV;
+    double *d_flux = nullptr, *d_flim = nullptr, *d_vol = nullptr, *d_phi = nullptr, *d_sums = nullptr;
+    int* d_bin = nullptr;
+    long long* d_idx = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    int rc = LF_OK;
+    auto ok = [&](hipError_t e) {
+        if (e != hipSuccess && rc == LF_OK) rc = LF_ERR_HIP;
+        return e == hipSuccess;
+    };
+    if (ok(hipMalloc((void**)&d_flux, nb)) && ok(hipMalloc((void**)&d_flim, nb)) && ok(hipMalloc((void**)&d_phi, nb)) &&
+        (!vol || ok(hipMalloc((void**)&d_vol, nb)))) {
+        ok(hipMemcpy(d_flux, flux, nb, hipMemcpyHostToDevice));
+        ok(hipMemcpy(d_flim, flim, nb, hipMemcpyHostToDevice));
+        if (vol) ok(hipMemcpy(d_vol, vol, nb, hipMemcpyHostToDevice));
+        double ratio = 0.0;
+        if (fcmin > 0.0) {
+            const double a = (2.0 * fcmin - 1.0) * (2.0 * fcmin - 1.0);      // VmaxLumFunc.py:164
+            ratio = std::fabs(a / (1.0 - a));
+        }
+        if (rc == LF_OK) {
+            hipLaunchKernelGGL(lf::veff_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_flux, d_flim, d_vol, vol_all, pref0,
+                               alpha, ratio, fcmin > 0.0 ? 1 : 0, (long long)n, d_phi);
+            ok(hipGetLastError());
+        }
+        if (rc == LF_OK && nbin > 0) {
+            const size_t sb = (size_t)(nboot + 1) * nbin * sizeof(double);
+            if (ok(hipMalloc((void**)&d_bin, (size_t)n * sizeof(int))) && ok(hipMalloc((void**)&d_sums, sb)) &&
+                (!boot_idx || ok(hipMalloc((void**)&d_idx, (size_t)n * nboot * sizeof(long long))))) {
+                ok(hipMemcpy(d_bin, bin_of, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+                ok(hipMemset(d_sums, 0, sb));
+                if (boot_idx) ok(hipMemcpy(d_idx, boot_idx, (size_t)n * nboot * sizeof(long long), hipMemcpyHostToDevice));
+                if (rc == LF_OK) {
+                    const unsigned gx = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
+                    hipLaunchKernelGGL(lf::veff_bins, dim3(gx, (unsigned)(nboot + 1)), dim3(256), 0, 0, d_phi, d_bin, (long long)n, nbin,
+                                       d_idx, (unsigned long long)seed, d_sums);
+                    ok(hipGetLastError());
+                    ok(hipMemcpy(sums, d_sums, sb, hipMemcpyDeviceToHost));
+                }
+            }
+        }
+        if (rc == LF_OK) ok(hipMemcpy(phi, d_phi, nb, hipMemcpyDeviceToHost));
+    }
+    hipFree(d_flux); hipFree(d_flim); hipFree(d_vol); hipFree(d_phi); hipFree(d_sums); hipFree(d_bin); hipFree(d_idx);
+    return rc;
+}
+
 int lf_last_launch(const lf_ctx* c, int32_t info[8]) {
     if (!c || !info) return LF_ERR_ARG;
     for (int i = 0; i < 8; ++i) info[i] = c->last_launch[i];

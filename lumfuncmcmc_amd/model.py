@@ -282,6 +282,19 @@ class _Base(object):
             for j, v in enumerate(np.percentile(nsamples, per, axis=0)):
                 self.table[-1][(i + start_value + j * n)] = v
 
+    def _veff(self, sum_Omega, zmaxval, device):
+        if device is None:
+            device = self._ctx is not None
+        if device:
+            vol = veff.comoving_volume(self.dVdzf, self.zmin, zmaxval)
+            self.phifunc, self.Lavg, self.lfbinorig, self.var = veff.veff_device(
+                self.lum, self.flux, 1.0e-17 * self.Flims_arr, vol, sum_Omega, self.alpha, self.fcmin,
+                nboot=self.nboot, nbin=self.nbins, device=self.device)
+            return
+        self.phifunc = veff.lumfunc_weights(self.flux, self.dVdzf, sum_Omega, self.zmin, zmaxval,
+                                            1.0e-17 * self.Flims_arr, self.alpha, self.fcmin)
+        self.Lavg, self.lfbinorig, self.var = veff.boot_err_log(self.lum, self.phifunc, self.nboot, self.nbins)
+
     def _veff_or_skip(self):
         try:
             self.VeffLF()
@@ -412,8 +425,10 @@ class LumFuncMCMC(_Base):
         self.Flim, self.alpha = list(np.median(Flims, axis=0)), np.median(alphas)
         self._veff_or_skip()
 
-    def VeffLF(self):
-        """1/Veff weights per source and the binned LF with bootstrap errors (lumfuncmcmc.py:515-525)."""
+    def VeffLF(self, device=None):
+        """1/Veff weights per source and the binned LF with bootstrap errors (lumfuncmcmc.py:515-525).  device=True
+        runs weights, binning and bootstrap on the GPU (lf_veff; resamples drawn with Philox instead of numpy's global
+        state), False on the host; None = the GPU when this object already holds a device context."""
         self.getFlim()
         sum_Omega = sum(self.Omega_0)
         if self.min_comp_frac <= 0.001:
@@ -421,9 +436,7 @@ class LumFuncMCMC(_Base):
         else:
             root = self.rootsf.ev(self.Flims_arr, self.alpha)
             zmaxval = np.minimum(self.zmax, veff.max_redshift(10 ** self.lum, root, _cosmo))
-        self.phifunc = veff.lumfunc_weights(self.flux, self.dVdzf, sum_Omega, self.zmin, zmaxval,
-                                            1.0e-17 * self.Flims_arr, self.alpha, self.fcmin)
-        self.Lavg, self.lfbinorig, self.var = veff.boot_err_log(self.lum, self.phifunc, self.nboot, self.nbins)
+        self._veff(sum_Omega, zmaxval, device)
 
     def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
         raise NotImplementedError("triangle_plot needs corner/matplotlib; plotting is outside the scope of this build (use set_median_fit)")
@@ -545,16 +558,14 @@ class LumFuncMCMCz(_Base):
                                            self.phi1, self.phi2, self.phi3, self.z1, self.z2, self.z3)
         self._veff_or_skip()
 
-    def VeffLF(self):
-        """lumfuncmcmc_z.py:470-478."""
+    def VeffLF(self, device=None):
+        """lumfuncmcmc_z.py:470-478 (device: see LumFuncMCMC.VeffLF)."""
         sum_Omega = sum(self.Omega_0)
         if self.min_comp_frac <= 0.001:
             zmaxval = self.zmax
         else:
             zmaxval = np.minimum(self.zmax, veff.max_redshift(10 ** self.lum, self.roots_arr, _cosmo))
-        self.phifunc = veff.lumfunc_weights(self.flux, self.dVdzf, sum_Omega, self.zmin, zmaxval,
-                                            1.0e-17 * self.Flims_arr, self.alpha, self.fcmin)
-        self.Lavg, self.lfbinorig, self.var = veff.boot_err_log(self.lum, self.phifunc, self.nboot, self.nbins)
+        self._veff(sum_Omega, zmaxval, device)
 
     def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
         raise NotImplementedError("triangle_plot needs corner/matplotlib; plotting is outside the scope of this build (use set_median_fit)")

@@ -11,8 +11,8 @@ the integral (VmaxLumFunc.py:215-233).  So the weight of source i is
 
 and with min_comp_frac <= 0.001 the integral is the same for every source: one quadrature instead
 of N.  The bootstrap is a bincount per resample instead of nboot x nbins boolean masks over the
-catalogue.  Host NumPy: O(N), no kernel needed (N = 10^6: < 1 s; the reference needs N quad calls
-plus 5000 N-long masks).
+catalogue.  Host NumPy is O(N) (N = 10^6: ~1 s; the reference needs N quad calls plus 5000 N-long masks);
+`veff_device` does the weights, the binning and the nboot resamples in two HIP kernels (lf_veff).
 """
 import numpy as np
 
@@ -75,6 +75,18 @@ def max_redshift(lum_lin, fmin, cosmo, z0=1.5):
     return out
 
 
+def comoving_volume(dVdzf, zmin, zmaxval):
+    """int_{zmin}^{zmax} dV/dz dz of the docstring: one scipy.quad for a scalar zmax (as V.lumfunc evaluates it), the
+    exact integral of the interpolant per source otherwise; 0 where zmax <= zmin."""
+    if np.ndim(zmaxval) == 0:
+        if not zmaxval > zmin:
+            return 0.0
+        from scipy.integrate import quad
+        return quad(lambda z: float(dVdzf(z)), zmin, zmaxval)[0]
+    ok = zmaxval > zmin
+    return np.where(ok, _interp_integral(dVdzf, zmin, np.where(ok, zmaxval, zmin)), 0.0)
+
+
 def lumfunc_weights(flux, dVdzf, sum_omega, zmin, zmaxval, flim, alpha, fcmin):
     """phi_i of the docstring.  zmaxval: scalar (shared integral, evaluated with scipy.quad exactly
     as V.lumfunc does) or per-source array (exact integral of the interpolant; the reference's
@@ -93,6 +105,35 @@ def lumfunc_weights(flux, dVdzf, sum_omega, zmin, zmaxval, flim, alpha, fcmin):
     with np.errstate(divide="ignore"):
         phi[ok] = 1.0 / (pref[ok] * vol[ok])
     return phi
+
+
+def luminosity_bins(L, nbin):
+    """Bin edges, centres, width and the bin index of every source (nbin = no bin) of V.getBootErrLog."""
+    L = np.asarray(L, dtype=np.float64)
+    Larr = np.linspace(min(L) * 1.001, max(L), nbin + 1)
+    Lavg = np.linspace((Larr[0] + Larr[1]) / 2.0, (Larr[-1] + Larr[-2]) / 2.0, len(Larr) - 1)
+    idx = np.searchsorted(Larr, L, side="right") - 1
+    idx[(L < Larr[0]) | (L >= Larr[-1])] = nbin
+    return Larr, Lavg, Lavg[1] - Lavg[0], idx
+
+
+def veff_device(L, flux, flim, vol, sum_omega, alpha, fcmin, nboot=100, nbin=25, seed=None, boot_idx=None, device=0):
+    """VeffLF on the GPU (lf_veff of include/lfmcmc.h): the per-source weights, the binned LF and the bootstrap sums in
+    two kernels.  vol: the comoving-volume integral, scalar (min_comp_frac <= 0.001) or per source.  The resamples are
+    drawn on the device (Philox keyed by `seed`, default: one draw from numpy's global state) unless `boot_idx`
+    (nboot, N) is given - e.g. the reference's own seeded np.random.randint stream, which then reproduces
+    V.getBootErrLog's variances exactly.  Returns (phifunc, Lavg, lfbinorig, var) as lumfunc_weights + boot_err_log do."""
+    from .capi import veff_device as _dev
+    _, Lavg, dL, idx = luminosity_bins(L, nbin)
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    phi, sums = _dev(flux, flim, vol, sum_omega / hs.SQARCSEC, alpha, fcmin, bin_of=idx, nbin=nbin, nboot=nboot,
+                     boot_idx=boot_idx, seed=seed, device=device)
+    lfbin = sums[1:] / dL
+    binavg = np.average(lfbin, axis=0)
+    var = 1. / (nboot - 1) * np.sum((lfbin - binavg) ** 2, axis=0)
+    var[var <= 0.0] = min(var[var > 0.0])
+    return phi, Lavg, sums[0] / dL, var
 
 
 def boot_err_log(L, phi, nboot=100, nbin=25):

@@ -334,10 +334,19 @@ def main():
     #      are stored (a few KB) - the test rebuilds the catalogue with synth.catalogue and goes through
     #      the build's own host setup, so setup + kernels are compared with the reference together
     if only in (None, "e2e"):
-        for (variant, n, seed, zsl, nrows) in (("free", 100000, 20241016, 0, 12), ("free", 1000000, 20241016, 0, 12),
-                                               ("fixcomp", 1000000, 20241016, 0, 12), ("zevol", 800000, 20241016, 8, 12)):
+        # (name, variant, n, zslices, fix_sch_al, min_comp_frac, faint source)
+        cases = (("e2e_free_n100000", "free", 100000, 0, False, 0.0, True),
+                 ("e2e_free_n1000000", "free", 1000000, 0, False, 0.0, True),
+                 ("e2e_fixcomp_n1000000", "fixcomp", 1000000, 0, False, 0.0, False),
+                 ("e2e_zevol_n800000", "zevol", 800000, 8, False, 0.0, False),
+                 ("e2e_free_fsa_n100000", "free", 100000, 0, True, 0.0, False),
+                 ("e2e_free_mcf50_n100000", "free", 100000, 0, False, 0.5, False))
+        for (name, variant, n, zsl, fsa, mcf, faint) in cases:
+            seed = 20241016
             cat = S.catalogue(n, seed=seed, zslices=zsl)
-            kw = ctor_kwargs(cat, False, variant == "fixcomp", 0.0)
+            if faint:
+                cat["lum"][5] = 39.75          # one source ~1.9 dex below the 50 % flux of field 0: SLOW-mode walkers
+            kw = ctor_kwargs(cat, fsa, variant == "fixcomp", mcf)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 with np.errstate(all="ignore"):
@@ -349,12 +358,41 @@ def main():
                     else:
                         o = R.LumFuncMCMC(S.split_fields(cat["z"], cat["field_ind"]), **kw)
                         f = o.lnprob_fix_comp if variant == "fixcomp" else o.lnprob
-                    th = S.walkers(variant, nrows, seed=1)
-                    if variant != "zevol":
-                        th[-1, 0] = 40.3          # one row in the underflow zone
+                    # 48 rows: 32 in the finite box; the underflow zone; the prior's edges (on them, 1e-9 outside);
+                    # (free, faint source) walkers whose bounds cannot exclude underflow
+                    th = S.walkers(variant, 48, seed=1, fix_sch_al=fsa)
+                    nd = th.shape[1]
+                    if variant == "zevol":
+                        th[32, 0] = S.LSTAR_LIMS[0]                  # strict for L and phi (lumfuncmcmc_z.py:355-358): -inf
+                        th[33, 0] = S.LSTAR_LIMS[0] + 1e-9
+                        th[34, 2] = S.LSTAR_LIMS[1]
+                        th[35, 2] = S.LSTAR_LIMS[1] - 1e-9
+                        th[36, 3] = S.PHISTAR_LIMS[1]
+                        th[37, 5] = S.PHISTAR_LIMS[0] + 1e-9
+                        if not fsa:
+                            th[38, 6] = S.SCH_AL_LIMS[0]             # inclusive for alpha (:351-353)
+                            th[39, 6] = S.SCH_AL_LIMS[1] + 1e-9
+                        th[40:44, 0:3] = np.array([[40.2, 40.3, 40.4], [40.6, 40.5, 40.4], [41.0, 40.2, 41.0], [40.9, 40.9, 40.9]])
+                    else:
+                        th[32, 0] = 40.3                             # underflow zone
+                        th[33, 0] = S.LSTAR_LIMS[1]                  # inclusive box (lumfuncmcmc.py:346-358)
+                        th[34, 0] = S.LSTAR_LIMS[1] + 1e-9
+                        th[35, 1] = S.PHISTAR_LIMS[0]
+                        th[36, 1] = S.PHISTAR_LIMS[0] - 1e-9
+                        if not fsa:
+                            th[37, 2] = S.SCH_AL_LIMS[1]
+                            th[38, 2] = S.SCH_AL_LIMS[0] - 1e-9
+                        if variant == "free":
+                            th[39, nd - 1] = S.ALPHA_LIMS[1]
+                            th[40, nd - 1] = S.ALPHA_LIMS[1] + 1e-9
+                            th[41, nd - 6] = S.FLIM_LIMS[0]
+                            th[42, nd - 2] = S.FLIM_LIMS[1] + 1e-9
+                            th[43:48, nd - 6] = np.linspace(1.2, 5.9, 5)   # Flim of field 0 ...
+                            th[43:48:2, nd - 1] = 6.9                      # ... under a steep completeness curve
                     lnp = np.array([f(np.array(t)) for t in th])
-            save("e2e_%s_n%d" % (variant, n), dict(variant=variant, n=n, seed=seed, zslices=zsl, theta=th, lnprob=lnp))
-            print(variant, n, lnp[:3])
+            save(name, dict(variant=variant, n=n, seed=seed, zslices=zsl, fix_sch_al=fsa, min_comp_frac=mcf,
+                            faint=int(faint), theta=th, lnprob=lnp))
+            print(name, lnp[:3], "-inf rows", int(np.isinf(lnp).sum()))
     if only:
         with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)

@@ -109,3 +109,37 @@ def compare_rows(got, ref, inp, thetas, rtol, what="lnprob"):
         worst = max(worst, rel)
         assert rel <= rtol, "%s row %d: got %.17g ref %.17g rel %.3e" % (what, i, got[i], ref[i], rel)
     return worst
+
+
+def e2e_model(g, **extra):
+    """The model object of an end-to-end fixture (tests/golden/e2e_*.npz, oracle/gen_golden.py --only e2e): the catalogue
+    is regenerated from the generator arguments the fixture stores and goes through the build's own host setup."""
+    from lumfuncmcmc_amd.model import LumFuncMCMC, LumFuncMCMCz
+    variant, n = str(g["variant"]), int(g["n"])
+    cat = synth.catalogue(n, seed=int(g["seed"]), zslices=int(g["zslices"]))
+    if "faint" in g.files and int(g["faint"]):
+        cat["lum"][5] = 39.75                  # the fixture's one source far below the flux limit of field 0
+    fi = cat["field_ind"]
+    fsa = bool(g["fix_sch_al"]) if "fix_sch_al" in g.files else False
+    mcf = float(g["min_comp_frac"]) if "min_comp_frac" in g.files else 0.0
+    kw = dict(lum=synth.split_fields(cat["lum"], fi), lum_e=synth.split_fields(cat["lum_e"], fi),
+              Flim=list(synth.FLIM), alpha=synth.ALPHA_C, Omega_0=list(synth.OMEGA_0), sch_al=synth.SCH_AL,
+              sch_al_lims=synth.SCH_AL_LIMS, Lstar=synth.LSTAR, Lstar_lims=synth.LSTAR_LIMS,
+              phistar=synth.PHISTAR, phistar_lims=synth.PHISTAR_LIMS, Lc=synth.LC, Lh=synth.LH, nwalkers=32,
+              nsteps=10, min_comp_frac=mcf, field_ind=fi, fix_sch_al=fsa)
+    kw.update(extra)
+    zs = synth.split_fields(cat["z"], fi)
+    if variant == "zevol":
+        return LumFuncMCMCz(zs, **kw)
+    return LumFuncMCMC(zs, fix_comp=(variant == "fixcomp"), Flim_lims=synth.FLIM_LIMS, alpha_lims=synth.ALPHA_LIMS, **kw)
+
+
+def e2e_compare(o, g, rtol):
+    """lnprob of the fixture's theta rows through the class surface against the reference's own values."""
+    variant = str(g["variant"])
+    th = g["theta"]
+    got = o.lnprob_fix_comp(th) if variant == "fixcomp" else o.lnprob(th)
+    ref = g["lnprob"]
+    inp = o.kernel_inputs()
+    inp["lims"] = {k: list(v) for k, v in inp["lims"].items()}
+    return compare_rows(got, ref, inp, th, rtol), int(np.isinf(ref).sum())
