@@ -166,7 +166,8 @@ def compressed_leg(ctx, step, fence, direct_out, steps, W):
     res = {"value": W * steps / dt, "unit": "walker-lnprob evals/s", "ms_per_step": dt / steps * 1e3,
            "build_s": build_s, "max_rel_diff_vs_direct": rel,
            "note": "opt-in option, off by default; piece A over weighted pseudo-sources and (free variant, separable grid) "
-                   "piece B over shared flux nodes, a-priori error bound of 1e-16 per bin"}
+                   "piece B over shared flux nodes; bins validated at sampled walkers of the prior box (not a proven bound) "
+                   "and self-checked against the direct path at build time"}
     # the same catalogue with 2048 walkers (cost per evaluation no longer depends on N: more walkers fill the GPU)
     try:
         from lumfuncmcmc_amd import synth

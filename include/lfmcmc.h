@@ -129,15 +129,18 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * "taper": 1 gives the last ~B/8 walkers quarter-size tiles, dispatched last, so that the launch drains evenly
  * (bitwise neutral: a tile only decides which workgroup owns a (chunk, walker) sum); +1 % at N = 1e6 but the tail
  * tiles read the catalogue a second time (L2 -> fabric traffic 37 MB instead of 21 MB per launch): off by default.
- * "compress": 1 = take piece A from the COMPRESSED CATALOGUE (FREE, ZEVOL; off by default): the ~N sources of a
- * field are replaced by K = 16 weighted pseudo-sources per bin of the one coordinate the walker-dependent factor
- * of a term depends on (log flux; redshift), with bins refined until the bound on the relative error of every
- * bin sum, over the whole prior box, is below 1e-16 (csrc/lf_compress.h).  lnprob then costs the grid integral
- * plus a few hundred terms, whatever N is.  Walkers that need the per-source underflow checks are still summed
- * over the real catalogue.  Built at the first call with value 1 (returns LF_ERR_ARG if the bound cannot be met).
+ * "compress": 1 = take piece A from the COMPRESSED CATALOGUE (FREE, ZEVOL; off by default; never the headline path): the
+ * ~N sources of a field are replaced by K = 16 weighted pseudo-sources per bin of the one coordinate the walker-dependent
+ * factor of a term depends on (log flux; redshift).  Bins are halved until an ESTIMATE of the relative error of every
+ * bin sum is below 1e-16; the estimate is evaluated at sampled walkers of the prior box (FREE: 7 slopes alpha_C x up to
+ * 96 shifts of the flux limit, 33 points per bin; ZEVOL: the 8 corners of the (L1, L2, L3) box) - a sampled validation,
+ * NOT a bound proven over the whole box (csrc/lf_compress.h).  In addition a freshly built compressed catalogue must
+ * reproduce the direct path to 1e-12 on 64 walkers drawn from this context's prior box, or the option is refused
+ * (LF_ERR_ARG).  lnprob then costs the grid integral plus a few hundred terms, whatever N is.  Walkers that need the
+ * per-source underflow checks are still summed over the real catalogue.  Built at the first call with value 1.
  * With it, FREE contexts whose integration grid is separable (every redshift column has the same luminosity nodes:
  * min_comp_frac = 0) also take piece B over ~40 x 16 shared flux nodes per field instead of the S^2 lattice points
- * (same bound; "compress_grid" = 0 keeps the full grid).
+ * (same sampled validation; "compress_grid" = 0 keeps the full grid).
  * "tables": 1 (default) lets the free variant evaluate the term as the product of two tabulated univariate factors,
  * g(num) = ln fc and h(y) = 1 / (1 - e^(-10^y)) (piecewise degree-7 polynomials, relative error <= 8e-15 over their
  * whole domain, lf_tables.h), for (walker, chunk) pairs whose fluxes lie inside the tables and whose lanes of
@@ -204,7 +207,7 @@ int lf_sampler_half_accept(lf_sampler *s, int half, const double *d_newlp, void 
 /* Host-only helper behind "compress", exported for tests (touches no GPU): compress n coordinates `key` with
  * weights `wt` (NULL = 1) into pseudo-sources.  kind 0 (FREE): params = {|a/(1-a)|, alpha_lo, alpha_hi, flim_lo,
  * flim_hi}; kind 1 (ZEVOL): params = {L_lo, L_hi, z1, z2, z3}.  Returns the number of pseudo-sources (written to
- * node / weight when it is <= cap), or a negative code; *bound = the accepted error bound. */
+ * node / weight when it is <= cap), or a negative code; *bound = the largest accepted (sampled) error estimate. */
 int64_t lf_compress_keys(int kind, const double *params, const double *key, const double *wt, int64_t n,
                          double *node, double *weight, int64_t cap, double *bound);
 

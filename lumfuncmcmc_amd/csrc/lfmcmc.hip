@@ -694,6 +694,71 @@ int build_compressed(lf_ctx* c) {
     return LF_OK;
 }
 
+// see lf_set_option("compress"): direct vs compressed lnprob on 64 in-prior theta rows of this context
+int compress_selfcheck(lf_ctx* c) {
+    using namespace lf;
+    const int B = 64, nd = c->kc.ndim, nf = c->kc.nf;
+    std::vector<double> th((size_t)B * nd), direct(B), comp(B);
+    uint64_t st = 0x9e3779b97f4a7c15ull;
+    auto uni = [&]() {                                  // splitmix64 -> [0, 1)
+        uint64_t z = (st += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return (double)((z ^ (z >> 31)) >> 11) * 1.1102230246251565e-16;
+    };
+    auto in = [&](int lim, double lo_frac) {            // a point of the prior interval `lim` (upper part for L*)
+        const double lo = c->kc.lims[lim][0], hi = c->kc.lims[lim][1];
+        return lo + (hi - lo) * (lo_frac + (1.0 - lo_frac) * uni());
+    };
+    for (int b = 0; b < B; ++b) {
+        double* t = th.data() + (size_t)b * nd;
+        int k = 0;
+        if (c->kc.variant == LF_ZEVOL) {
+            for (int i = 0; i < 3; ++i) t[k++] = in(LF_LIM_LSTAR, 0.3);     // (the faint end of the L* box is the underflow zone)
+            for (int i = 0; i < 3; ++i) t[k++] = in(LF_LIM_PHISTAR, 0.0);
+            if (!c->kc.fix_sch_al) t[k++] = in(LF_LIM_SCH_AL, 0.0);
+        } else {
+            t[k++] = in(LF_LIM_LSTAR, 0.3);
+            t[k++] = in(LF_LIM_PHISTAR, 0.0);
+            if (!c->kc.fix_sch_al) t[k++] = in(LF_LIM_SCH_AL, 0.0);
+            if (c->kc.variant == LF_FREE) {
+                for (int f = 0; f < nf; ++f) t[k++] = in(LF_LIM_FLIM, 0.0);
+                t[k++] = in(LF_LIM_ALPHA, 0.0);
+            }
+        }
+    }
+    const int64_t was = c->opt_compress;
+    int rc = ensure_workspace(c, B, 0, 0);
+    for (int pass = 0; pass < 2 && rc == LF_OK; ++pass) {
+        c->opt_compress = pass;
+        LF_HIP(c, hipMemcpy(c->d_theta, th.data(), th.size() * sizeof(double), hipMemcpyHostToDevice));
+        rc = enqueue(c, c->d_theta, B, c->d_out, nullptr, nullptr, c->stream);
+        if (rc != LF_OK) break;
+        LF_HIP(c, hipStreamSynchronize(c->stream));
+        LF_HIP(c, hipMemcpy(pass ? comp.data() : direct.data(), c->d_out, B * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    c->opt_compress = was;
+    if (rc != LF_OK) return rc;
+    double worst = 0.0;
+    int nfin = 0;
+    for (int b = 0; b < B; ++b) {
+        if (std::isinf(direct[b]) || std::isinf(comp[b])) {
+            if (direct[b] != comp[b]) worst = HUGE_VAL;
+            continue;
+        }
+        ++nfin;
+        worst = std::fmax(worst, std::fabs(comp[b] - direct[b]) / std::fmax(std::fabs(direct[b]), 1e-300));
+    }
+    if (!(worst <= 1.0e-12)) {
+        char msg[200];
+        std::snprintf(msg, sizeof(msg), "compress: the compressed catalogue differs from the direct path by %.3g (relative) on "
+                      "%d of 64 self-check walkers of this prior box: option refused", worst, nfin);
+        c->err = msg;
+        return LF_ERR_ARG;
+    }
+    return LF_OK;
+}
+
 void free_ctx(lf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
@@ -1227,8 +1292,17 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     if (std::strcmp(key, "compress") == 0) {
         if (value != 0) {
             hipSetDevice(c->device);
-            const int rc = build_compressed(c);
+            const bool fresh = !c->cmp.built;
+            int rc = build_compressed(c);
             if (rc != LF_OK) return rc;
+            // The bins were accepted on a SAMPLED estimate of the interpolation error (lf_compress.h).  Before a freshly
+            // built compressed catalogue may serve, it must also reproduce the direct path on walkers drawn from THIS
+            // context's prior box: 64 theta rows (deterministic stream), both paths, lnprob to 1e-12 and the same -inf
+            // pattern - otherwise the option is refused and the compressed tables are dropped.
+            if (fresh && c->cmp.built && (rc = compress_selfcheck(c)) != LF_OK) {
+                free_cmp(c->cmp);
+                return rc;
+            }
         }
         c->opt_compress = value != 0;
         return LF_OK;

@@ -139,3 +139,36 @@ def test_device_sampler_on_the_compressed_catalogue():
     np.testing.assert_allclose(lnp[:, -1], last, rtol=1e-13)
     assert 0.05 < ds.acceptance_fraction.mean() <= 1.0
     ctx.close()
+
+
+@pytest.mark.parametrize("lims", [{"Flim": [0.5, 9.0], "alpha": [0.6, 10.0]}, {"Flim": [2.0, 4.0], "alpha": [3.0, 5.0]},
+                                  {"Lstar": [41.0, 47.0], "phistar": [-9.0, 2.0]}])
+def test_compress_with_a_non_default_prior_box(lims):
+    """The bins are validated at sampled walkers of the context's own prior box and the finished tables must reproduce
+    the direct path on 64 more walkers of that box at build time (lf_set_option "compress"): with another box the option
+    is either refused (LFError) or - what is asserted then - as good as with the default one."""
+    from lumfuncmcmc_amd.capi import LFError
+    inp = make_inputs("free", 60000, seed=83)
+    inp["lims"] = dict(inp["lims"])
+    inp["lims"].update(lims)
+    ctx = ctx_of(inp, compress=False)
+    rng = np.random.default_rng(84)
+    L = inp["lims"]
+    th = synth.walkers("free", 80, seed=85)
+    th[:, 3:8] = rng.uniform(L["Flim"][0], L["Flim"][1], (80, 5))
+    th[:, 8] = rng.uniform(L["alpha"][0], L["alpha"][1], 80)
+    th[:, 0] = rng.uniform(max(L["Lstar"][0], 41.5), L["Lstar"][1], 80)
+    direct = ctx.lnprob_batch(th)
+    try:
+        ctx.set_option("compress", 1)
+    except LFError as e:
+        print("refused:", e)
+        assert np.array_equal(ctx.lnprob_batch(th), direct)          # and the direct path is untouched
+        ctx.close()
+        return
+    got = ctx.lnprob_batch(th)
+    assert np.array_equal(np.isinf(got), np.isinf(direct))
+    fin = np.isfinite(direct)
+    assert fin.sum() > 40
+    np.testing.assert_allclose(got[fin], direct[fin], rtol=1e-12)
+    ctx.close()
