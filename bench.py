@@ -298,8 +298,10 @@ def census(leg, used):
     import torch
     ctx = leg.ctx
     ctx.set_option("count_forms", 1)
-    for j in used:
-        leg.ev.evaluate_tensor(leg.blocks[j])
+    for j in used:                                  # this rank's own launches only: no collective (rank 0 runs this alone)
+        rows = leg.blocks[j][leg.row_lo:leg.row_lo + leg.rows_local]
+        if rows.shape[0]:
+            ctx.lnprob_torch(rows.contiguous())
     torch.cuda.synchronize()
     counts = ctx.form_counts()
     ctx.set_option("count_forms", 0)
