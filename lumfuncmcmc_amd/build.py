@@ -26,12 +26,17 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
+# -amdgpu-atomic-optimizer-strategy=None: lf_free's one-lane queue claims must stay plain returning atomics whose
+# result is waited for where it is USED (half an item later); the optimizer's wave-aggregated form reads it at once.
+CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+            "-Wno-unused-value", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+
+
 def build_library(force=False, verbose=True, extra_flags=()):
     """Compile the C-ABI library for gfx950.  Raises on failure."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"] + list(extra_flags) + ["-o", LIB] + SOURCES
+    cmd = [hipcc()] + CXXFLAGS + ["-fPIC", "-shared"] + list(extra_flags) + ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)

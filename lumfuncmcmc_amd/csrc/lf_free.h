@@ -81,6 +81,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
     for (int tile = ((int)blockIdx.x >> 3) % fa.ntiles; tile < fa.ntiles; tile += fa.tile_stride) {
         const int w0 = tile * PTW;
         const int nw = min(PTW, fa.B - w0);
+        __builtin_assume(nw >= 1 && nw <= PTW);
         int* __restrict__ q = fa.queues + tile * QSTRIDE;
         // next item of this tile: a node chunk while there are any (item = chunk), then a catalogue chunk of our XCD's
         // queue, or of the next queue that still has some (item = nchB + chunk); -1 = the tile is done
@@ -161,18 +162,22 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
                 const int kfirst = sa.chunk_keys[4 * c], klast = sa.chunk_keys[4 * c + 1], kamax = sa.chunk_keys[4 * c + 2];
                 // switch in: the chunk's sources, coalesced (instruction k of a wave reads 512 contiguous bytes), via LDS
+                // (opaque: what is derived from the thread number is recomputed here.  Kept across items it is spilled, and a
+                // reload from scratch between two loads waits for every load issued before it: eight round trips in a row.)
+                int t = tid;
+                asm volatile("" : "+v"(t));
                 {
                     double xs[ST];
+                    const double* __restrict__ src = sa.a1 + s0;
 #pragma unroll
-                    for (int k = 0; k < ST; ++k) xs[k] = sa.a1[(size_t)s0 + min(k * PB + tid, n - 1)];
-                    if (tid == 0) take_ticket();  // behind the loads: waiting for them does not wait for it
+                    for (int k = 0; k < ST; ++k) xs[k] = src[min(k * PB + t, n - 1)];
 #pragma unroll
-                    for (int k = 0; k < ST; ++k) red[k * PB + tid] = xs[k];
+                    for (int k = 0; k < ST; ++k) red[k * PB + t] = xs[k];
                 }
                 __syncthreads();                  // [A]
                 double x[ST];
                 {
-                    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(red + tid * ST);
+                    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(red + t * ST);
 #pragma unroll
                     for (int k = 0; k < ST / 2; ++k) {
                         const double2 a = x2[k];
@@ -181,8 +186,12 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     }
                 }
                 __syncthreads();                  // [B] the staging area becomes the reduction buffer again
+                // The claim for the next item: issued here, looked at after the walker loop - a returning atomic is waited
+                // for where its result is used (build.py keeps the compiler's atomic optimizer from using it at once), and
+                // nothing between here and there waits for memory.
+                if (tid == 0) take_ticket();
                 // slots past the end of the chunk hold copies of its last source
-                const int npad = ST - min(max(n - tid * ST, 0), ST);
+                const int npad = ST - min(max(n - t * ST, 0), ST);
                 // ---- pass 1: the walkers whose (walker, chunk) pair takes the table-driven form (the bulk)
                 int rest = 0;                     // bit w: walker w needs pass 2 (wave-uniform)
                 WalkerK pn = fetch(0, fld);       // the next walker's constants are read while this one's terms run
@@ -276,6 +285,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int g = min(c * PB + tid, na.nnodes - 1);
                 const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0, a3 = na.a3[g], a4 = na.a4[g];
                 const double a4min = fmin(na.a4min[2 * c], na.a4min[min(2 * c + 1, (na.nnodes + BLOCK - 1) / BLOCK - 1)]);   // wave-uniform
+                // (the loads have arrived before the claim is issued: a wait for them would wait for it as well)
+                asm volatile("" ::"v"(G), "v"(PG), "v"(W), "v"(a3), "v"(a4), "v"(a4min));
                 if (tid == 0) take_ticket();
                 const int nodes_here = min(PB, na.nnodes - c * PB);
 #pragma unroll 1

@@ -882,10 +882,10 @@ __device__ __forceinline__ double field_sum_bright(const KConst& kc, const doubl
     for (int f = 0; f < NF; ++f) {
         const double num = fma(alphaC, a3, uni(r[RF(f, F_CA)]));
         const double w = fma(num, frsqrt(fma(num, num, 1.0)), 1.0);
-        s = fma(0.5 * kc.om0_grid[f], w, s);
+        s = fma(kc.om0_grid[f], w, s);
     }
     asm volatile("; LF_END node_bright");
-    return s;
+    return 0.5 * s;      // (a power of two: the same bits as scaling every weight, and no scaled weights to keep in registers)
 }
 
 __device__ __forceinline__ double field_sum_nf(const KConst& kc, const double* __restrict__ r, double alphaC, double a3,

@@ -144,42 +144,10 @@ int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<i
             fl.push_back(f);
         }
     }
-    // Chunk order.  lf_main deals contiguous runs of chunk indices to the 8 XCDs (in dispatch order inside each run),
-    // and with the catalogue sorted by flux a chunk's cost depends on its rank in its field (bright chunks run
-    // term_free_noexp for most walkers).  So: deal the chunks round-robin into 8 groups (every group gets the same
-    // mix of ranks and fields: natural order would hand one XCD only full-cost chunks), and inside a group put the
-    // faint, expensive chunks first - longest first keeps the drain of the launch short.
-    {
-        const size_t n = st.size();
-        if (n > 8) {
-            std::vector<size_t> rank(n);                  // rank of the chunk inside its field (natural order is field-major)
-            for (size_t i = 0, r = 0; i < n; ++i) {
-                r = (i > 0 && fl[i] == fl[i - 1]) ? r + 1 : 0;
-                rank[i] = r;
-            }
-            std::vector<size_t> order;
-            order.reserve(n);
-            for (size_t g = 0; g < 8; ++g) {
-                std::vector<size_t> grp;
-                for (size_t i = g; i < n; i += 8) grp.push_back(i);
-                std::stable_sort(grp.begin(), grp.end(), [&](size_t a, size_t b) { return rank[a] < rank[b]; });
-                order.insert(order.end(), grp.begin(), grp.end());
-            }
-            std::vector<int> st2(n), ln2(n), fl2(n);
-            for (size_t i = 0; i < n; ++i) {
-                st2[i] = st[order[i]];
-                ln2[i] = ln[order[i]];
-                fl2[i] = fl[order[i]];
-            }
-            st.swap(st2);
-            ln.swap(ln2);
-            fl.swap(fl2);
-        }
-    }
-    // Keys for the table-driven form of the FREE term (lf_kernels.h: srcsum_free), rounded so that a key test that
+    // Keys for the table-driven form of the FREE term (lf_free.h), rounded so that a key test that
     // passes implies the real-valued condition: kfirst = floor, klast = ceil of (x - x0) 2^20 for the chunk's
     // faintest / brightest source; kamax = the largest alpha_C (x 2^16, floor) for which alpha_C times the widest
-    // lane of the chunk (a lane = ch / 256 neighbours in flux) stays within the g table's margin - 0 when that
+    // lane of the chunk (a lane = lane_w neighbours in flux) stays within the g table's margin - 0 when that
     // width already exceeds the h table's margin.  A chunk with a non-finite flux gets keys that fail every test.
     std::vector<int> keys(4 * st.size(), 0);
     for (size_t i = 0; i < st.size(); ++i) {
@@ -200,6 +168,48 @@ int get_chunks(lf_ctx* c, std::map<int, ChunkTable>& tables, const std::vector<i
         keys[4 * i] = (int)k0;
         keys[4 * i + 1] = (int)k1;
         keys[4 * i + 2] = (int)std::floor(std::fmin(amax, 3.0e4) * lf::KEY_ASCALE);
+    }
+    // Chunk order.  The kernels deal contiguous runs of chunk indices to the 8 XCDs (lf_main: in dispatch order inside
+    // each run; lf_free: one queue per run), and with the catalogue sorted by flux a chunk's cost depends on its rank
+    // in its field (bright chunks run the forms without the exponential for most walkers).  So: deal the chunks
+    // round-robin into 8 groups (every group gets the same mix of ranks and fields: natural order would hand one XCD
+    // only full-cost chunks), and inside a group put the expensive chunks first - longest first keeps the drain of
+    // the launch short: the faint ones before the bright ones, and, with lanes of flux-neighbours (lf_free), before
+    // both the chunks whose lanes are too wide for the tables at ordinary alpha_C (the sparse ends of a field: the
+    // general form, twice the cost per term).
+    {
+        const size_t n = st.size();
+        if (n > 8) {
+            std::vector<size_t> rank(n);                  // rank of the chunk inside its field (natural order is field-major)
+            for (size_t i = 0, r = 0; i < n; ++i) {
+                r = (i > 0 && fl[i] == fl[i - 1]) ? r + 1 : 0;
+                rank[i] = r;
+            }
+            const int wide = (int)(32.0 * lf::KEY_ASCALE);
+            auto cls = [&](size_t i) { return (lane_w > 0 && hx) ? std::min(keys[4 * i + 2], wide) : wide; };
+            std::vector<size_t> order;
+            order.reserve(n);
+            for (size_t g = 0; g < 8; ++g) {
+                std::vector<size_t> grp;
+                for (size_t i = g; i < n; i += 8) grp.push_back(i);
+                std::stable_sort(grp.begin(), grp.end(), [&](size_t a, size_t b) {
+                    const int ca = cls(a), cb = cls(b);
+                    return ca != cb ? ca < cb : rank[a] < rank[b];
+                });
+                order.insert(order.end(), grp.begin(), grp.end());
+            }
+            std::vector<int> st2(n), ln2(n), fl2(n), keys2(4 * n);
+            for (size_t i = 0; i < n; ++i) {
+                st2[i] = st[order[i]];
+                ln2[i] = ln[order[i]];
+                fl2[i] = fl[order[i]];
+                for (int j = 0; j < 4; ++j) keys2[4 * i + j] = keys[4 * order[i] + j];
+            }
+            st.swap(st2);
+            ln.swap(ln2);
+            fl.swap(fl2);
+            keys.swap(keys2);
+        }
     }
     ChunkTable t;
     t.n = (int)st.size();

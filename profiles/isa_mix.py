@@ -29,8 +29,9 @@ CYC_FP64, CYC_TRANS64, CYC_VALU32 = 4.0, 16.0, 2.5
 def assembly(hipcc="/opt/rocm/bin/hipcc"):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "lf.s")
-        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc",
-                        "-Wno-unused-value", "-S", "--cuda-device-only", "-o", out, SRC], check=True,
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from lumfuncmcmc_amd.build import CXXFLAGS          # the library's own flags
+        subprocess.run([hipcc] + CXXFLAGS + ["-S", "--cuda-device-only", "-o", out, SRC], check=True,
                        stderr=subprocess.DEVNULL)
         return open(out).read()
 

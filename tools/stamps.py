@@ -24,8 +24,8 @@ def main():
     src = os.path.join(ROOT, "lumfuncmcmc_amd", "csrc", "lfmcmc.hip")
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(ROOT, "lumfuncmcmc_amd", "csrc", f))
                                                               for f in os.listdir(os.path.join(ROOT, "lumfuncmcmc_amd", "csrc"))):
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-gpu-rdc",
-                        "-DLF_STAMPS", "-Wno-unused-value", "-o", lib, src], check=True)
+        from lumfuncmcmc_amd import build
+        subprocess.run([build.hipcc()] + build.CXXFLAGS + ["-fPIC", "-shared", "-DLF_STAMPS", "-o", lib, src], check=True)
     from lumfuncmcmc_amd import capi
     capi.LIB_PATH = lib
     import torch
