@@ -30,8 +30,8 @@ constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalo
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
 // (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
 __device__ __forceinline__ void reduce_store512(const double* __restrict__ red, int nw, double* __restrict__ out,
-                                                size_t stride, int w0, int chunk) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                                                size_t stride, int w0, int chunk, int tid) {
+    const int w = tid >> 6, lane = tid & 63;
     if (w < nw) {
         const double* row = red + w * PB + lane;
         double s0 = (row[0] + row[64]) + (row[128] + row[192]);
@@ -68,6 +68,17 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         tab.expt[i] = EXP_TABLE[i];
     }
     load_term_tables<PB>(&tt);
+    // The thread number, made anew wherever it is needed (wave index from a scalar register, lane from mbcnt on an opaque
+    // mask): what is derived from it - indices, addresses - is then computed where it is used.  Carried across the item
+    // loop such values were spilled - 30 MB of scratch stores per launch from the prologue alone - and a reload from
+    // scratch between two loads waits for every load issued before it: the eight loads of a switch-in took eight round
+    // trips (tools/stamps.py: 10k of an item's 31k cycles).
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    auto fresh_tid = [&]() -> int {
+        int m = -1;
+        asm volatile("" : "+s"(m));
+        return wave_base + __builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0));
+    };
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int myq = (int)(xcc & 7u);
@@ -85,8 +96,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         int* __restrict__ q = fa.queues + tile * QSTRIDE;
         // next item of this tile: a node chunk while there are any (item = chunk), then a catalogue chunk of our XCD's
         // queue, or of the next queue that still has some (item = nchB + chunk); -1 = the tile is done
+        int no_grid = fa.skip_grid;
+        asm volatile("" : "+s"(no_grid));                  // (made per tile: kept from the prologue it is the one value spilled)
         auto grab = [&]() -> int {
-            if (!fa.skip_grid && fa.nchB > 0) {
+            if (!no_grid && fa.nchB > 0) {
                 const int i = atomicAdd(q, 1);
                 if (i < fa.nchB) return i;
             }
@@ -99,11 +112,13 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             }
             return -1;
         };
-        // The claim of the item after the current one is split in two so that nobody waits for the atomic's round trip
-        // (2.3k cycles, tools/stamps.py): thread 0 takes a TICKET of the queue it expects to serve it - the grid queue
-        // until that has run dry once, then its XCD's catalogue queue - right after the current item's loads are
-        // issued, and turns it into an item (or falls back to the full search) only at the end of the walker loop.
-        bool grid_dry = fa.skip_grid || fa.nchB <= 0;      // (thread 0's view)
+        // The claim of the item after the current one rides on the current item's loads: thread 0 takes a TICKET of the
+        // queue it expects to serve it - the grid queue until that has run dry once, then its XCD's catalogue queue -
+        // just before the loads are issued, and turns it into an item (or falls back to the full search) when they have
+        // arrived: one round trip for both.  The result goes to LDS at once: kept in a register across the walker loop
+        // it is spilled, and the spill waits for the atomic on the spot.  (build.py keeps the compiler's atomic
+        // optimizer from reading the one-lane atomic's result where it is issued.)
+        bool grid_dry = no_grid || fa.nchB <= 0;           // (thread 0's view)
         int ticket = 0;
         auto take_ticket = [&]() { ticket = atomicAdd(grid_dry ? q + 1 + myq : q, 1); };
         auto redeem = [&]() -> int {
@@ -117,11 +132,12 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             return grab();                        // our queue is empty: steal (the grid queue and ours just hand out misses)
         };
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
-        if (tid == 0) sitem[0] = grab();
+        const int u = fresh_tid();
+        if (u == 0) sitem[0] = grab();
         // the tile's walker constants, all fields (64 B per (walker, field)), once
-        if (tid < nw * MAXF) {
-            const int w = tid / MAXF, f = tid - w * MAXF;
-            double* d = wfc + tid * 8;
+        if (u < nw * MAXF) {
+            const int w = u / MAXF, f = u - w * MAXF;
+            double* d = wfc + u * 8;
             int* di = reinterpret_cast<int*>(d + 4);
             if (f < kc.nf) {
                 // slot order of the record's own field block (F_V = 1, F_CA = 2, F_CY = 3), alpha_C in the slot of lF
@@ -135,8 +151,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 for (int i = 0; i < 5; ++i) di[i] = km[i];
             }
         }
-        if (tid >= PB - PTW * 8) {                // (the last 64 threads: walker w, scalar slot j)
-            const int t = tid - (PB - PTW * 8), w = t >> 3, j = t & 7;
+        if (u >= PB - PTW * 8) {                // (the last 64 threads: walker w, scalar slot j)
+            const int t = u - (PB - PTW * 8), w = t >> 3, j = t & 7;
             if (w < nw) wsc[t] = wrec[(size_t)(w0 + w) * REC + j];
         }
         __syncthreads();
@@ -156,23 +172,23 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #pragma unroll 1
         while (item >= 0) {
             __syncthreads();                      // [D] the previous item's reduction has read `red` (and sitem)
+            int t = fresh_tid();
             if (item >= fa.nchB) {
                 // ================= catalogue chunk: piece A =================
                 const int c = item - fa.nchB;
-                const int s0 = sa.chunk_start[c], n = sa.chunk_len[c], fld = sa.chunk_field[c];
-                const int kfirst = sa.chunk_keys[4 * c], klast = sa.chunk_keys[4 * c + 1], kamax = sa.chunk_keys[4 * c + 2];
+                // (wave-uniform by construction; said so, or they sit - and are spilled - in vector registers)
+                const int s0 = uni(sa.chunk_start[c]), n = uni(sa.chunk_len[c]), fld = uni(sa.chunk_field[c]);
+                const int kfirst = uni(sa.chunk_keys[4 * c]), klast = uni(sa.chunk_keys[4 * c + 1]), kamax = uni(sa.chunk_keys[4 * c + 2]);
                 // switch in: the chunk's sources, coalesced (instruction k of a wave reads 512 contiguous bytes), via LDS
-                // (opaque: what is derived from the thread number is recomputed here.  Kept across items it is spilled, and a
-                // reload from scratch between two loads waits for every load issued before it: eight round trips in a row.)
-                int t = tid;
-                asm volatile("" : "+v"(t));
                 {
                     double xs[ST];
                     const double* __restrict__ src = sa.a1 + s0;
+                    if (t == 0) take_ticket();    // in front of the loads: back when they are
 #pragma unroll
                     for (int k = 0; k < ST; ++k) xs[k] = src[min(k * PB + t, n - 1)];
 #pragma unroll
                     for (int k = 0; k < ST; ++k) red[k * PB + t] = xs[k];
+                    if (t == 0) sitem[0] = redeem();
                 }
                 __syncthreads();                  // [A]
                 double x[ST];
@@ -186,10 +202,6 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     }
                 }
                 __syncthreads();                  // [B] the staging area becomes the reduction buffer again
-                // The claim for the next item: issued here, looked at after the walker loop - a returning atomic is waited
-                // for where its result is used (build.py keeps the compiler's atomic optimizer from using it at once), and
-                // nothing between here and there waits for memory.
-                if (tid == 0) take_ticket();
                 // slots past the end of the chunk hold copies of its last source
                 const int npad = ST - min(max(n - t * ST, 0), ST);
                 // ---- pass 1: the walkers whose (walker, chunk) pair takes the table-driven form (the bulk)
@@ -207,21 +219,21 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                             table_lookup<ST>(C, x, p, true, &tt);
                             acc = table_terms<ST, true>(C, x, npad);
                             asm volatile("; LF_END table_noexp");
-                            if (CENSUS && kc.forms && tid == 0) atomicAdd(kc.forms + FORM_TABLE_NOEXP, (unsigned long long)n);
+                            if (CENSUS && kc.forms && t == 0) atomicAdd(kc.forms + FORM_TABLE_NOEXP, (unsigned long long)n);
                         } else {
                             asm volatile("; LF_BEGIN table items=%0" ::"n"(ST));
                             table_lookup<ST>(C, x, p, false, &tt);
                             acc = table_terms<ST, false>(C, x, npad);
                             asm volatile("; LF_END table");
-                            if (CENSUS && kc.forms && tid == 0) atomicAdd(kc.forms + FORM_TABLE, (unsigned long long)n);
+                            if (CENSUS && kc.forms && t == 0) atomicAdd(kc.forms + FORM_TABLE, (unsigned long long)n);
                         }
                     } else if (p.mode < MODE_SKIP) {
                         rest |= 1 << w;
-                    } else if (CENSUS && kc.forms && tid == 0) {
+                    } else if (CENSUS && kc.forms && t == 0) {
                         // -inf already (outside the prior, or the brightest source underflows): nothing to sum
                         atomicAdd(kc.forms + FORM_SKIPPED, (unsigned long long)n);
                     }
-                    red[w * PB + tid] = acc;
+                    red[w * PB + t] = acc;
                 }
                 // ---- pass 2 (rare at the catalogue sizes this kernel serves): pairs outside the tables' reach - the
                 // sparse tails of a field, extreme walkers - in the general form (lf_math.h: table exp / log, one rsqrt
@@ -229,6 +241,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 // poisoning).  Sources re-read from memory in a rolled loop: none of this may claim registers next to
                 // the table form's.
                 if (rest) {
+                    t = fresh_tid();              // (pass 2's addresses are made here, not carried through pass 1)
                     const double a1_first = sa.a1[s0], u_first = sa.U[s0];      // sorted by flux: the chunk's faintest
 #pragma unroll 1
                     for (int w = 0; w < nw; ++w) {
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                             const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
                                            r[RF(fld, F_LF)], r[RF(fld, F_V)], kc.lnom0_src[fld], 0.0};
 #pragma unroll 1
-                            for (int i = tid; i < n; i += PB) {
+                            for (int i = t; i < n; i += PB) {
                                 const size_t g = (size_t)s0 + i;
                                 acc += term_free_careful(wf, sa.lum[g], sa.a1[g], sa.P[g], sa.U[g]);
                             }
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                             if (upper && u_first * wf.V > 37.5) {
                                 form = FORM_GENERAL_NOEXP;
 #pragma unroll 1
-                                for (int i = tid; i < n; i += PB) {
+                                for (int i = t; i < n; i += PB) {
                                     asm volatile("; LF_BEGIN general_noexp items=1");
                                     acc += term_free_noexp(wf, sa.a1[(size_t)s0 + i], &tab);
                                     asm volatile("; LF_END general_noexp");
@@ -263,31 +276,31 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                             } else {
                                 form = FORM_GENERAL;
 #pragma unroll 1
-                                for (int i = tid; i < n; i += PB) {
+                                for (int i = t; i < n; i += PB) {
                                     asm volatile("; LF_BEGIN general items=1");
                                     acc += term_free_fast(wf, sa.a1[(size_t)s0 + i], sa.U[(size_t)s0 + i], &tab);
                                     asm volatile("; LF_END general");
                                 }
                             }
                         }
-                        if (CENSUS && kc.forms && tid == 0) atomicAdd(kc.forms + form, (unsigned long long)n);
-                        red[w * PB + tid] = acc;
+                        if (CENSUS && kc.forms && t == 0) atomicAdd(kc.forms + form, (unsigned long long)n);
+                        red[w * PB + t] = acc;
                     }
                 }
-                if (tid == 0) sitem[0] = redeem();
                 __syncthreads();                  // [C]
-                reduce_store512(red, nw, fa.partA, (size_t)fa.nchA, w0, c);
+                t = fresh_tid();
+                reduce_store512(red, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
                 item = sitem[0];
             } else {
                 // ================= node chunk: piece B =================
                 const int c = item;
-                const bool valid = c * PB + tid < na.nnodes;
-                const int g = min(c * PB + tid, na.nnodes - 1);
+                const bool valid = c * PB + t < na.nnodes;
+                const int g = min(c * PB + t, na.nnodes - 1);
+                if (t == 0) take_ticket();        // in front of the loads: back when they are
                 const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0, a3 = na.a3[g], a4 = na.a4[g];
                 const double a4min = fmin(na.a4min[2 * c], na.a4min[min(2 * c + 1, (na.nnodes + BLOCK - 1) / BLOCK - 1)]);   // wave-uniform
-                // (the loads have arrived before the claim is issued: a wait for them would wait for it as well)
-                asm volatile("" ::"v"(G), "v"(PG), "v"(W), "v"(a3), "v"(a4), "v"(a4min));
-                if (tid == 0) take_ticket();
+                asm volatile("" ::"v"(G), "v"(PG), "v"(W), "v"(a3), "v"(a4), "v"(a4min));      // (the loads have arrived)
+                if (t == 0) sitem[0] = redeem();
                 const int nodes_here = min(PB, na.nnodes - c * PB);
 #pragma unroll 1
                 for (int w = 0; w < nw; ++w) {
@@ -302,16 +315,16 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                         double vmin = r[RF(0, F_V)];
                         for (int f = 1; f < kc.nf; ++f) vmin = fmin(vmin, r[RF(f, F_V)]);
                         const bool bright = kc.specialise && alphaC > 0.0 && a4min * uni(vmin) > 37.5;
-                        if (CENSUS && kc.forms && tid == 0)
+                        if (CENSUS && kc.forms && t == 0)
                             atomicAdd(kc.forms + (bright ? FORM_NODE_BRIGHT : FORM_NODE_GENERAL), (unsigned long long)(nodes_here * kc.nf));
                         const double s = field_sum_nf(kc, r, alphaC, a3, a4, &tab, bright);
                         val = W * T * s;
                     }
-                    red[w * PB + tid] = val;
+                    red[w * PB + t] = val;
                 }
-                if (tid == 0) sitem[0] = redeem();
                 __syncthreads();                  // [C]
-                reduce_store512(red, nw, fa.partB, (size_t)fa.nchB, w0, c);
+                t = fresh_tid();
+                reduce_store512(red, nw, fa.partB, (size_t)fa.nchB, w0, c, t);
                 item = sitem[0];
             }
 #ifdef LF_STAMPS

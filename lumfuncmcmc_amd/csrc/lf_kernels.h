@@ -429,6 +429,8 @@ __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 struct WFree {   // wave-uniform walker constants of one (walker, field)
     double Lstar, c0f, c1, Q, alphaC, lF, V, lnom0, cA;
 };

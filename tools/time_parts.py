@@ -44,7 +44,7 @@ def main():
             spec, 1e3 * kt["main"]["ms"] / kt["main"]["launches"], 1e3 * kt["prepare"]["ms"] / kt["prepare"]["launches"],
             1e3 * kt["finalize"]["ms"] / kt["finalize"]["launches"], ctx.last_launch()), flush=True)
         for k, v in opts:
-            ctx.set_option(k, {"tables": 1, "specialise": 1}.get(k, 0))
+            ctx.set_option(k, {"tables": 1, "specialise": 1, "persistent": 1}.get(k, 0))      # back to the defaults
 
 
 if __name__ == "__main__":
