@@ -36,6 +36,12 @@ class _Base(object):
                                    # "sources" = every rank holds 1/world of the catalogue and of the grid and evaluates
                                    # every walker (all-reduce of lnprob) - for ensembles too small to split by walker
 
+    @staticmethod
+    def _check_shard(shard):
+        if shard not in ("walkers", "sources"):
+            raise ValueError("shard must be 'walkers' or 'sources', not %r" % (shard,))
+        return shard
+
     # ------------------------------------------------------------------ setup (host, once)
     def _common_init(self, z, flux, flux_e, lum, lum_e):
         self.z = np.concatenate(z)
@@ -318,10 +324,11 @@ class LumFuncMCMC(_Base):
                  nboot=100, sch_al=-1.6, sch_al_lims=[-3.0, 1.0], Lstar=42.5, Lstar_lims=[40.0, 45.0],
                  phistar=-3.0, phistar_lims=[-8.0, 5.0], Lc=40.0, Lh=46.0, nwalkers=100, nsteps=1000,
                  fix_sch_al=False, fcmin=0.1, fix_comp=False, min_comp_frac=0.5,
-                 field_names=None, field_ind=None, diff_rand=True, device=0, compress=False):
+                 field_names=None, field_ind=None, diff_rand=True, device=0, compress=False, shard="walkers"):
         self._common_init(z, flux, flux_e, lum, lum_e)
         self.device = device
         self.compress = bool(compress)
+        self.shard = self._check_shard(shard)
         self.fcmin, self.min_comp_frac = fcmin, min_comp_frac
         self.Flim, self.Flim_lims = Flim, Flim_lims
         self.fields, self.nfields = field_names, len(self.Flim)
@@ -455,10 +462,11 @@ class LumFuncMCMCz(_Base):
                  nboot=100, sch_al=-1.6, sch_al_lims=[-3.0, 1.0], Lstar=42.5, Lstar_lims=[41.0, 45.0],
                  phistar=-3.0, phistar_lims=[-8.0, 5.0], Lc=40.0, Lh=46.0, nwalkers=100, nsteps=1000,
                  fcmin=0.1, min_comp_frac=0.5, field_names=None,
-                 field_ind=None, z1=1.20, z2=1.53, z3=1.86, fix_sch_al=False, device=0, compress=False):
+                 field_ind=None, z1=1.20, z2=1.53, z3=1.86, fix_sch_al=False, device=0, compress=False, shard="walkers"):
         self._common_init(z, flux, flux_e, lum, lum_e)
         self.device = device
         self.compress = bool(compress)
+        self.shard = self._check_shard(shard)
         self.z1, self.z2, self.z3 = z1, z2, z3
         self.fcmin, self.min_comp_frac = fcmin, min_comp_frac
         self.Flim = Flim
