@@ -41,8 +41,8 @@ def main():
         ctx.set_profiling(0)
         kt = ctx.kernel_times()
         print("%-28s lf_main %.1f us  prepare %.1f us  finalize %.1f us  launch %s" % (
-            spec, 1e3 * kt["main"]["ms"] / kt["main"]["launches"], 1e3 * kt["prepare"]["ms"] / kt["prepare"]["launches"],
-            1e3 * kt["finalize"]["ms"] / kt["finalize"]["launches"], ctx.last_launch()), flush=True)
+            spec, 1e3 * kt["main"]["ms"] / max(kt["main"]["launches"], 1), 1e3 * kt["prepare"]["ms"] / max(kt["prepare"]["launches"], 1),
+            1e3 * kt["finalize"]["ms"] / max(kt["finalize"]["launches"], 1), ctx.last_launch()), flush=True)
         for k, v in opts:
             ctx.set_option(k, {"tables": 1, "specialise": 1, "persistent": 1}.get(k, 0))      # back to the defaults
 
