@@ -467,7 +467,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     // the persistent kernel takes the free variant's direct path whenever the catalogue can fill it and no launch
     // geometry of lf_main was asked for explicitly
     if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
-        !(c->opt_compress && c->cmp.built) && c->N >= 32768) {
+        !(c->opt_compress && c->cmp.built) && (c->N >= 32768 || c->opt_persistent == 2)) {
         // Measured crossover (B = 128: lf_main 42 / 48 / 68 / 109 / 167 us at N = 1e5 / 1.25e5 / 2.5e5 / 5e5 / 1e6, lf_free
         // 67 / 66 / 70 / 94 / 137): the persistent kernel wins once every one of its ~512 workgroups gets about four
         // items or more (items = 4096-source chunks and 512-node chunks per tile of 8 walkers; N >~ 4.4e5 at 128 rows);

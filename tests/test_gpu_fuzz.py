@@ -51,6 +51,41 @@ def test_random_configuration(seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configuration_persistent_kernel(seed):
+    """The same ragged shapes through lf_free (persistent workgroups, table-driven term; forced: it normally serves
+    catalogues of 4e5 sources and more), every sources-per-lane instantiation, against the oracle."""
+    from lumfuncmcmc_amd.capi import LFContext
+    rng = np.random.default_rng(3000 + seed)
+    nf = int(rng.integers(1, 9))
+    n = int(rng.choice([1, 2, 7, 63, 511, 513, 2049, 4095, 4096, 4097, 9000, 33000]))
+    S = int(rng.integers(4, 40))
+    fsa = bool(rng.integers(0, 2))
+    inp = make_inputs("free", n, seed=100 + seed, S=S, fix_sch_al=fsa, nf=nf)
+    cuts = np.sort(rng.integers(0, n + 1, nf - 1)) if nf > 1 else np.array([], dtype=int)      # ragged fields, some empty
+    inp["field_ind"] = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    if seed % 4 == 1:
+        # steep number counts with a sparse bright tail: lanes too wide for the tables -> the general forms of pass 2
+        lum = inp["lum"]
+        inp["lum"] = np.minimum(lum.min() + rng.exponential(0.3, n), 43.5)
+        inp["lum"][0] = lum.min()
+    B = int(rng.choice([1, 7, 8, 9, 33, 64, 70, 130]))
+    th = synth.walkers("free", B, seed=seed + 11, fix_sch_al=fsa, nf=nf)
+    if B > 3:
+        th[0, 0] = 40.2                     # underflow zone
+        th[1, 1] = 5.5                      # outside the prior
+        th[2, -1] = np.nan
+    ref = O.lnprob_batch(inp, th)
+    ctx = LFContext(inp)
+    ctx.set_option("persistent", 2)
+    for st in (0, int(rng.choice([2, 4]))):
+        ctx.set_option("free_st", st)
+        got = ctx.lnprob_batch(th)
+        assert ctx.last_launch()["kernel"].startswith("lf_free"), ctx.last_launch()
+        compare_rows(got, ref, inp, th, RTOL, "seed %d st %d" % (seed, st))
+    ctx.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_large_catalogue_compressed(seed):
     """Catalogues big enough for every bin to be compressed, with skewed source distributions: compressed

@@ -10,6 +10,11 @@ for seed in range(a, b):
         F.test_random_configuration(seed)
     except Exception as e:                      # keep going: report every failing seed
         bad.append((seed, repr(e)[:200]))
+for seed in range(a, b):
+    try:
+        F.test_random_configuration_persistent_kernel(seed)
+    except Exception as e:
+        bad.append(("persistent", seed, repr(e)[:200]))
 for seed in range(a, a + (b - a) // 10):
     try:
         F.test_random_large_catalogue_compressed(seed)
