@@ -84,8 +84,12 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
     const int myq = (int)(xcc & 7u);
 #ifdef LF_STAMPS
     unsigned long long* stamp = kc.stamps ? kc.stamps + (size_t)blockIdx.x * 8 : nullptr;
-    if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+    if (stamp && tid == 0) {
+        stamp[0] = __builtin_amdgcn_s_memtime();
+        stamp[5] = __builtin_amdgcn_s_memrealtime();
+    }
     int nitems_done = 0;
+    unsigned long long t_first = 0, t_sw = 0, t_loop = 0, t_red = 0;
 #endif
 
 #pragma unroll 1
@@ -171,6 +175,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 
 #pragma unroll 1
         while (item >= 0) {
+#ifdef LF_STAMPS
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            if (t_first == 0) t_first = ta;
+            unsigned long long tb = ta, tc = ta;
+#endif
             __syncthreads();                      // [D] the previous item's reduction has read `red` (and sitem)
             int t = fresh_tid();
             if (item >= fa.nchB) {
@@ -202,6 +211,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     }
                 }
                 __syncthreads();                  // [B] the staging area becomes the reduction buffer again
+#ifdef LF_STAMPS
+                tb = __builtin_amdgcn_s_memtime();
+#endif
                 // slots past the end of the chunk hold copies of its last source
                 const int npad = ST - min(max(n - t * ST, 0), ST);
                 // ---- pass 1: the walkers whose (walker, chunk) pair takes the table-driven form (the bulk)
@@ -287,6 +299,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                         red[w * PB + t] = acc;
                     }
                 }
+#ifdef LF_STAMPS
+                tc = __builtin_amdgcn_s_memtime();
+#endif
                 __syncthreads();                  // [C]
                 t = fresh_tid();
                 reduce_store512(red, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
@@ -329,6 +344,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             }
 #ifdef LF_STAMPS
             ++nitems_done;
+            if (tb != ta) {
+                t_sw += tb - ta;
+                t_loop += tc - tb;
+                t_red += __builtin_amdgcn_s_memtime() - tc;
+            }
 #endif
         }
     }
@@ -336,7 +356,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
     if (stamp && tid == 0) {
         stamp[1] = __builtin_amdgcn_s_memtime();
         stamp[2] = (unsigned long long)nitems_done;
+        stamp[3] = t_first ? t_first - stamp[0] : 0;      // prologue: tables, tile constants, first claim
+        stamp[4] = t_sw;                                  // catalogue items: barrier D, loads, LDS transposition (wave 0's view)
+        stamp[7] = t_loop;                                //                  walker loops
         stamp[6] = __builtin_amdgcn_s_memrealtime();
+        kc.stamps[(size_t)gridDim.x * 8 + blockIdx.x] = t_red;      // barrier C, reduction, stores  (second table behind the first)
     }
 #endif
 }

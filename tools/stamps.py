@@ -44,12 +44,16 @@ def main():
         ctx.lnprob_torch(th)
     torch.cuda.synchronize()
     nb = ctx.last_launch()["workgroups"]
-    assert L.lf_debug_stamps(ctx._h, None, nb) == 0
+    assert L.lf_debug_stamps(ctx._h, None, nb + (nb + 7) // 8) == 0      # 8 slots per workgroup + one more table of nb values
     for _ in range(3):
         ctx.lnprob_torch(th)
     torch.cuda.synchronize()
-    out = np.zeros((nb, 8), dtype=np.uint64)
-    assert L.lf_debug_stamps(ctx._h, out.ctypes.data_as(ctypes.c_void_p), nb) == 0
+    nrow = nb + (nb + 7) // 8
+    out = np.zeros((nrow, 8), dtype=np.uint64)
+    assert L.lf_debug_stamps(ctx._h, out.ctypes.data_as(ctypes.c_void_p), nrow) == 0
+    t_red = out.reshape(-1)[nb * 8: nb * 8 + nb].astype(np.int64)
+    out = out[:nb]
+    t_red = t_red[out[:, 0] > 0]
     s = out[out[:, 0] > 0].astype(np.int64)
     print("workgroups stamped: %d of %d in the launch" % (len(s), nb))
     life = s[:, 1] - s[:, 0]
@@ -60,6 +64,13 @@ def main():
     print("shader cycles per workgroup (thread 0): life", q(life))
     print("items per workgroup                        ", q(items), " total", items.sum())
     print("cycles per item                            ", q(life / np.maximum(items, 1)))
+    pm = lambda x: q(x / np.maximum(life, 1) * 1000)
+    print("per mille of the workgroup's life (wave 0): prologue up to the first item   ", pm(s[:, 3]))
+    print("   catalogue items: barrier D + loads + LDS transposition + barriers A, B    ", pm(s[:, 4]))
+    print("                    walker loops (passes 1 and 2)                            ", pm(s[:, 7]))
+    print("                    barrier C + reduction + stores                           ", pm(t_red))
+    print("   the rest (node chunks, tile set-up, end)                                  ", pm(life - s[:, 3] - s[:, 4] - s[:, 7] - t_red))
+    print("start spread %.1f us; first start to last end %.1f us" % ((s[:, 5].max() - s[:, 5].min()) / 100.0, (s[:, 6].max() - s[:, 5].min()) / 100.0))
     rt = s[:, 6]
     print("spread of the workgroups' end times: %.1f us" % ((rt.max() - rt.min()) / 100.0))
 
