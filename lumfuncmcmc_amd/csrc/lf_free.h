@@ -57,8 +57,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                                                  const int* __restrict__ wmode, FreeArgs fa) {
     __shared__ MathTables tab;
     __shared__ TermTables tt;
-    __shared__ __attribute__((aligned(16))) double red[(ST > PTW ? ST : PTW) * PB];   // reduction buffer = staging area of the items
-    __shared__ __attribute__((aligned(16))) double wfc[PTW * MAXF * 8];   // per (walker, field): aC, V, cA, cY, {mode, klo, khi, kne, kaC}
+    __shared__ __attribute__((aligned(16))) double red[PTW * PB];         // per-walker lane sums of the item in hand
+    __shared__ __attribute__((aligned(16))) double wfc[PTW * MAXF * 8];   // per (walker, field): aC, V, cA, cYs, {mode, klo, khi, kne, kaC}, cYH
     __shared__ __attribute__((aligned(16))) double wsc[PTW * 8];          // per walker: L*, c0, c1, Q, alpha_C
     __shared__ int sitem[2];
     const int tid = threadIdx.x;
@@ -150,7 +150,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 d[0] = r[R_ALPHAC];
                 d[F_V] = r[RF(f, F_V)];
                 d[F_CA] = r[RF(f, F_CA)];
-                d[F_CY] = r[RF(f, F_CY)];
+                // (the h table's index arithmetic wants y - H_LO, and that minus half a piece: table_lookup)
+                d[F_CY] = r[RF(f, F_CY)] - H_LO - 0.5 / H_INV;
+                d[7] = r[RF(f, F_CY)] - H_LO;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) di[i] = km[i];
             }
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         // while this one waits for its item at switch-in.)
         auto fetch = [&](int w, int fld) {        // uniform LDS address: broadcast reads
             const double2* __restrict__ p = reinterpret_cast<const double2*>(wfc + (w * MAXF + fld) * 8);
-            const double2 a = p[0], b = p[1];
+            const double2 a = p[0], b = p[1], c = p[3];
             const int4 k = *reinterpret_cast<const int4*>(p + 2);
-            const int k4 = *reinterpret_cast<const int*>(p + 3);
-            return WalkerK{a.x, b.x, b.y, a.y, __builtin_amdgcn_readfirstlane(k.x), __builtin_amdgcn_readfirstlane(k.y),
-                           __builtin_amdgcn_readfirstlane(k.z), __builtin_amdgcn_readfirstlane(k.w), __builtin_amdgcn_readfirstlane(k4)};
+            return WalkerK{a.x, b.x, b.y, c.y, __builtin_amdgcn_readfirstlane(k.x), __builtin_amdgcn_readfirstlane(k.y),
+                           __builtin_amdgcn_readfirstlane(k.z), __builtin_amdgcn_readfirstlane(k.w),
+                           __builtin_amdgcn_readfirstlane(__double2loint(c.x))};
         };
 
 #pragma unroll 1
@@ -188,29 +190,31 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 // (wave-uniform by construction; said so, or they sit - and are spilled - in vector registers)
                 const int s0 = uni(sa.chunk_start[c]), n = uni(sa.chunk_len[c]), fld = uni(sa.chunk_field[c]);
                 const int kfirst = uni(sa.chunk_keys[4 * c]), klast = uni(sa.chunk_keys[4 * c + 1]), kamax = uni(sa.chunk_keys[4 * c + 2]);
-                // switch in: the chunk's sources, coalesced (instruction k of a wave reads 512 contiguous bytes), via LDS
-                {
-                    double xs[ST];
-                    const double* __restrict__ src = sa.a1 + s0;
-                    if (t == 0) take_ticket();    // in front of the loads: back when they are
-#pragma unroll
-                    for (int k = 0; k < ST; ++k) xs[k] = src[min(k * PB + t, n - 1)];
-#pragma unroll
-                    for (int k = 0; k < ST; ++k) red[k * PB + t] = xs[k];
-                    if (t == 0) sitem[0] = redeem();
-                }
-                __syncthreads();                  // [A]
+                // switch in: every lane loads its own ST flux-neighbours, 64 contiguous bytes (four 16-byte loads; the four
+                // touch the same cache lines).  Not the coalesced pattern - a wave instruction spans 4 KB - but the kernel
+                // streams 8 MB per launch against hundreds of microseconds of arithmetic: what counted was the staging
+                // through LDS it replaces (a transposition and two more workgroup barriers per item, 17 % of a
+                // workgroup's life in tools/stamps.py).  Slots past the end of a ragged chunk hold copies of its last source.
                 double x[ST];
-                {
-                    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(red + t * ST);
+                if (t == 0) take_ticket();        // in front of the loads: back when they are
+                if (n == PB * ST) {               // (wave-uniform; all but the last chunk of a field)
+                    typedef double __attribute__((ext_vector_type(2), aligned(8))) double2_a8;      // (chunks start at any source)
+                    const double2_a8* __restrict__ src = reinterpret_cast<const double2_a8*>(sa.a1 + s0 + t * ST);
 #pragma unroll
                     for (int k = 0; k < ST / 2; ++k) {
-                        const double2 a = x2[k];
+                        const double2_a8 a = src[k];
                         x[2 * k] = a.x;
                         x[2 * k + 1] = a.y;
                     }
+                } else {
+                    const double* __restrict__ src = sa.a1 + s0;
+#pragma unroll
+                    for (int k = 0; k < ST; ++k) x[k] = src[min(t * ST + k, n - 1)];
                 }
-                __syncthreads();                  // [B] the staging area becomes the reduction buffer again
+                if (t == 0) {
+                    asm volatile("" ::"v"(x[ST - 1]));              // (the loads - and the claim issued before them - have arrived)
+                    sitem[0] = redeem();
+                }
 #ifdef LF_STAMPS
                 tb = __builtin_amdgcn_s_memtime();
 #endif

@@ -735,7 +735,8 @@ struct TabCoef {       // one lane's pieces of g and h for one walker, and the a
     double sa, sc, dy;
 };
 struct WalkerK {       // wave-uniform constants of one (walker, field), read from the LDS copy
-    double aC, cA, cY, V;
+    double aC, cA;          // num = aC x + cA
+    double cYs, cYH;        // y - H_LO = x + cYH;  cYs = cYH - 1 / (2 H_INV): round(H_INV (x + cYs)) = floor(H_INV (y - H_LO))
     int mode, klo, khi, kne, kac;
 };
 
@@ -743,16 +744,18 @@ template <int ST>
 __device__ __forceinline__ void table_lookup(TabCoef& C, const double (&x)[ST], const WalkerK& p, bool noexp,
                                              const TermTables* __restrict__ tt) {
     const double xc = x[ST / 2];
-    // g: binade of v = |num| + 1 and its top G_BITS mantissa bits
+    // g: binade of v = |num| + 1 and its top G_BITS mantissa bits.  The sign of num selects the half of the table and
+    // flips the affine map - by bit operations on the high words, no compare / select pairs.
     const double numc = fma(p.aC, xc, p.cA);
+    const int nh = __double2hiint(numc);
+    const int sgn = nh & (int)0x80000000u;
     const double v = fabs(numc) + 1.0;
     const int hi = __double2hiint(v) & (int)(0xffffffffu << (20 - G_BITS));
     const double vlo = __hiloint2double(hi, 0);
-    const bool neg = numc < 0.0;
-    int pg = (hi >> (20 - G_BITS)) - (0x3ff << G_BITS) + (neg ? G_NPOS : 0);
+    int pg = (hi >> (20 - G_BITS)) + ((nh >> 31) & G_NPOS) - (0x3ff << G_BITS);
     pg = min(max(pg, 0), G_N - 1);
-    C.sa = neg ? -p.aC : p.aC;                                // t_i = |num_i| + 1 - v_lo = sa x_i + sc
-    C.sc = (neg ? -p.cA : p.cA) + (1.0 - vlo);
+    C.sa = __hiloint2double(__double2hiint(p.aC) ^ sgn, __double2loint(p.aC));            // t_i = |num_i| + 1 - v_lo = sa x_i + sc
+    C.sc = __hiloint2double(__double2hiint(p.cA) ^ sgn, __double2loint(p.cA)) + (1.0 - vlo);
     const double2* __restrict__ g2 = reinterpret_cast<const double2*>(tt->g) + pg * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -762,9 +765,13 @@ __device__ __forceinline__ void table_lookup(TabCoef& C, const double (&x)[ST], 
     }
     C.dy = 0.0;
     if (!noexp) {                                             // (wave-uniform)
-        const double yq = fmin(fmax((xc + p.cY - H_LO) * (double)H_INV, 0.0), (double)(H_N - 1));
-        const int ph = (int)yq;                               // floor: yq >= 0
-        C.dy = p.cY - (H_LO + (double)ph * (1.0 / H_INV));    // t_i = y_i - y_lo = x_i + dy
+        // h: piece floor(H_INV (y - H_LO)) by magic-number rounding (the index is the low word of the sum: no
+        // conversions); a tie goes to either neighbour, both valid there (H_MARGIN).  The clamp only matters for
+        // values the key tests never let through (NaN).
+        constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
+        const double tq = fma(xc + p.cYs, (double)H_INV, MAGIC);
+        const int ph = min(max(__double2loint(tq), 0), H_N - 1);
+        C.dy = fma(tq - MAGIC, -1.0 / H_INV, p.cYH);          // t_i = y_i - y_lo = x_i + dy
         const double2* __restrict__ h2 = reinterpret_cast<const double2*>(tt->h) + ph * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -811,14 +818,15 @@ __device__ __forceinline__ double table_terms(const TabCoef& C, const double (&x
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
+            const bool first = k0 + k < 4;        // (the accumulator's first term: no add of 0.0, which the compiler keeps)
             if (NOEXP) {
-                acc4[k & 3] += p[k];
+                acc4[k & 3] = first ? p[k] : acc4[k & 3] + p[k];
                 if (k0 + k == ST - 1) last = p[k];
             } else if (k0 + k == ST - 1) {
                 last = p[k] * q[k];
-                acc4[k & 3] += last;
+                acc4[k & 3] = first ? last : acc4[k & 3] + last;
             } else {
-                acc4[k & 3] = fma(p[k], q[k], acc4[k & 3]);
+                acc4[k & 3] = first ? p[k] * q[k] : fma(p[k], q[k], acc4[k & 3]);
             }
         }
         if (k0 + CH < ST) __builtin_amdgcn_sched_barrier(0);      // keep the batches apart (registers)

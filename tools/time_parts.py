@@ -20,7 +20,11 @@ def main():
     ap.add_argument("--rows", type=int, default=128)
     ap.add_argument("--variant", default="free")
     ap.add_argument("--sets", default="default;skip_grid=1;tables=0;tables=0,skip_grid=1;specialise=0")
+    ap.add_argument("--lib", default="", help="A/B: another build of the library (path to a .so)")
     a = ap.parse_args()
+    if a.lib:
+        from lumfuncmcmc_amd import capi
+        capi.LIB_PATH = os.path.abspath(a.lib)
     model = bench.build_model(a.variant, a.nsrc, 2 * a.rows, 0)
     ctx = model.context()
     th = [torch.from_numpy(synth.walkers(a.variant, a.rows, seed=s)).cuda() for s in (1, 2, 3, 4)]
