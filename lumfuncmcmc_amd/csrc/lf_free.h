@@ -169,10 +169,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         auto fetch = [&](int w, int fld) {        // uniform LDS address: broadcast reads
             const double2* __restrict__ p = reinterpret_cast<const double2*>(wfc + (w * MAXF + fld) * 8);
             const double2 a = p[0], b = p[1], c = p[3];
-            const int4 k = *reinterpret_cast<const int4*>(p + 2);
-            return WalkerK{a.x, b.x, b.y, c.y, __builtin_amdgcn_readfirstlane(k.x), __builtin_amdgcn_readfirstlane(k.y),
-                           __builtin_amdgcn_readfirstlane(k.z), __builtin_amdgcn_readfirstlane(k.w),
-                           __builtin_amdgcn_readfirstlane(__double2loint(c.x))};
+            // mode and keys: scalar loads straight from lf_prepare's table (wave-uniform address; five readfirstlanes
+            // per walker fewer than through the LDS copy)
+            const int* __restrict__ km = wmode + ((size_t)(w0 + w) * MAXF + fld) * WM;
+            return WalkerK{a.x, b.x, b.y, c.y, km[M_MODE], km[M_KLO], km[M_KHI], km[M_KNE], km[M_KAC]};
         };
 
 #pragma unroll 1
