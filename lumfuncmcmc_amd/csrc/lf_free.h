@@ -189,7 +189,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int c = item - fa.nchB;
                 // (wave-uniform by construction; said so, or they sit - and are spilled - in vector registers)
                 const int s0 = uni(sa.chunk_start[c]), n = uni(sa.chunk_len[c]), fld = uni(sa.chunk_field[c]);
-                const int kfirst = uni(sa.chunk_keys[4 * c]), klast = uni(sa.chunk_keys[4 * c + 1]), kamax = uni(sa.chunk_keys[4 * c + 2]);
+                // (kamax: the largest alpha_C key for which THIS WAVE's lanes fit one table piece each)
+                const int kfirst = uni(sa.chunk_keys[KEY_STRIDE * c]), klast = uni(sa.chunk_keys[KEY_STRIDE * c + 1]),
+                          kamax = uni(sa.chunk_keys[KEY_STRIDE * c + 4 + (wave_base >> 6)]);
                 // switch in: every lane loads its own ST flux-neighbours, 64 contiguous bytes (four 16-byte loads; the four
                 // touch the same cache lines).  Not the coalesced pattern - a wave instruction spans 4 KB - but the kernel
                 // streams 8 MB per launch against hundreds of microseconds of arithmetic: what counted was the staging
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #endif
                 // slots past the end of the chunk hold copies of its last source
                 const int npad = ST - min(max(n - t * ST, 0), ST);
+                const int nwave = min(max(n - wave_base * ST, 0), 64 * ST);      // real sources of this wave (census)
                 // ---- pass 1: the walkers whose (walker, chunk) pair takes the table-driven form (the bulk)
                 int rest = 0;                     // bit w: walker w needs pass 2 (wave-uniform)
                 WalkerK pn = fetch(0, fld);       // the next walker's constants are read while this one's terms run
@@ -235,19 +238,19 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                             table_lookup<ST>(C, x, p, true, &tt);
                             acc = table_terms<ST, true>(C, x, npad);
                             asm volatile("; LF_END table_noexp");
-                            if (CENSUS && kc.forms && t == 0) atomicAdd(kc.forms + FORM_TABLE_NOEXP, (unsigned long long)n);
+                            if (CENSUS && kc.forms && (t & 63) == 0) atomicAdd(kc.forms + FORM_TABLE_NOEXP, (unsigned long long)nwave);
                         } else {
                             asm volatile("; LF_BEGIN table items=%0" ::"n"(ST));
                             table_lookup<ST>(C, x, p, false, &tt);
                             acc = table_terms<ST, false>(C, x, npad);
                             asm volatile("; LF_END table");
-                            if (CENSUS && kc.forms && t == 0) atomicAdd(kc.forms + FORM_TABLE, (unsigned long long)n);
+                            if (CENSUS && kc.forms && (t & 63) == 0) atomicAdd(kc.forms + FORM_TABLE, (unsigned long long)nwave);
                         }
                     } else if (p.mode < MODE_SKIP) {
                         rest |= 1 << w;
-                    } else if (CENSUS && kc.forms && t == 0) {
+                    } else if (CENSUS && kc.forms && (t & 63) == 0) {
                         // -inf already (outside the prior, or the brightest source underflows): nothing to sum
-                        atomicAdd(kc.forms + FORM_SKIPPED, (unsigned long long)n);
+                        atomicAdd(kc.forms + FORM_SKIPPED, (unsigned long long)nwave);
                     }
                     red[w * PB + t] = acc;
                 }
@@ -258,7 +261,17 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 // the table form's.
                 if (rest) {
                     t = fresh_tid();              // (pass 2's addresses are made here, not carried through pass 1)
-                    const double a1_first = sa.a1[s0], u_first = sa.U[s0];      // sorted by flux: the chunk's faintest
+                    // The general forms run on the wave's own lanes (its sources are in registers; whether a pair takes the
+                    // table form is decided per wave) and also need 10^(logf + 17).  Only the careful path, which every
+                    // wave of the chunk takes together (the mode is the walker's), strides over the whole chunk.
+                    double u[ST];
+                    {
+                        const double* __restrict__ up = sa.U + s0;
+#pragma unroll
+                        for (int k = 0; k < ST; ++k) u[k] = up[min(t * ST + k, n - 1)];
+                    }
+                    const double a1_first = uni(x[0]), u_first = uni(u[0]);     // sorted by flux: the wave's faintest source
+                    const int nmine = ST - npad;                                // real sources of this lane
 #pragma unroll 1
                     for (int w = 0; w < nw; ++w) {
                         if (!((rest >> w) & 1)) continue;
@@ -283,23 +296,27 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                             const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
                             if (upper && u_first * wf.V > 37.5) {
                                 form = FORM_GENERAL_NOEXP;
-#pragma unroll 1
-                                for (int i = t; i < n; i += PB) {
+#pragma unroll
+                                for (int k = 0; k < ST; ++k) {
                                     asm volatile("; LF_BEGIN general_noexp items=1");
-                                    acc += term_free_noexp(wf, sa.a1[(size_t)s0 + i], &tab);
+                                    const double term = term_free_noexp(wf, x[k], &tab);
                                     asm volatile("; LF_END general_noexp");
+                                    acc += k < nmine ? term : 0.0;
+                                    __builtin_amdgcn_sched_barrier(0);      // one term at a time (registers)
                                 }
                             } else {
                                 form = FORM_GENERAL;
-#pragma unroll 1
-                                for (int i = t; i < n; i += PB) {
+#pragma unroll
+                                for (int k = 0; k < ST; ++k) {
                                     asm volatile("; LF_BEGIN general items=1");
-                                    acc += term_free_fast(wf, sa.a1[(size_t)s0 + i], sa.U[(size_t)s0 + i], &tab);
+                                    const double term = term_free_fast(wf, x[k], u[k], &tab);
                                     asm volatile("; LF_END general");
+                                    acc += k < nmine ? term : 0.0;
+                                    __builtin_amdgcn_sched_barrier(0);
                                 }
                             }
                         }
-                        if (CENSUS && kc.forms && t == 0) atomicAdd(kc.forms + form, (unsigned long long)n);
+                        if (CENSUS && kc.forms && (t & 63) == 0) atomicAdd(kc.forms + form, (unsigned long long)nwave);
                         red[w * PB + t] = acc;
                     }
                 }

@@ -33,6 +33,7 @@ namespace lf {
 constexpr int BLOCK = 256;   // 4 waves
 constexpr int MAXF = 8;
 constexpr int REC = 8 + 8 * MAXF;   // doubles per walker record: 8 walker scalars, then one block of 8 per field
+constexpr int KEY_STRIDE = 12;   // ints per chunk in SrcArrays::chunk_keys
 constexpr int WM = 8;        // ints per (walker, field) in wmode: {mode, klo, khi, kne, kaC, -, -, -}
 // SKIP: the walker failed the prior - lnprob is -inf whatever the sums are (the reference returns before lnlike,
 // lumfuncmcmc.py:408): neither its terms nor its grid nodes are evaluated.  SKIPSRC: piece A is already known to be
@@ -537,7 +538,8 @@ struct SrcArrays {
     const int* chunk_start;
     const int* chunk_len;
     const int* chunk_field;
-    const int* chunk_keys;   // FREE, real catalogue: per chunk {kfirst, klast, kamax, -} (lfmcmc.hip: get_chunks), else NULL
+    const int* chunk_keys;   // FREE, real catalogue: KEY_STRIDE ints per chunk {kfirst, klast, kamax, -, kamax of waves 0..7}
+                             // (lfmcmc.hip: get_chunks), else NULL
     int* queue;              // FREE, real catalogue: the eight per-XCD item counters of the persistent workgroups
 };
 
