@@ -483,14 +483,14 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     // geometry of lf_main was asked for explicitly
     if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
         !(c->opt_compress && c->cmp.built) && (c->N >= 32768 || c->opt_persistent == 2)) {
-        // Measured crossover (B = 128: lf_main 42 / 48 / 68 / 109 / 167 us at N = 1e5 / 1.25e5 / 2.5e5 / 5e5 / 1e6, lf_free
-        // 67 / 66 / 70 / 94 / 137): the persistent kernel wins once every one of its ~512 workgroups gets about four
-        // items or more (items = 4096-source chunks and 512-node chunks per tile of 8 walkers; N >~ 4.4e5 at 128 rows);
-        // below that its coarse items cost more than its tables save.
+        // Measured crossover (B = 128: lf_main 42 / 48 / 55 / 68 / 110 / 167 us at N = 1e5 / 1.25e5 / 1.8e5 / 2.5e5 / 5e5 /
+        // 1e6, lf_free 60 / 51 / 52 / 57 / 78 / 122; B = 256 at N = 1.25e5: 78 against 69): the persistent kernel wins once
+        // every one of its ~512 workgroups gets about two items or more (items = 4096-source chunks and 512-node chunks
+        // per tile of 8 walkers; N >~ 1.8e5 at 128 rows); below that its coarse items cost more than its tables save.
         // opt_persistent = 2 or an explicit free_st force it (tests, tuning runs).
         const int64_t ntiles = (B + PTW - 1) / PTW;
         const int64_t items = ((c->N + 8 * (int64_t)PB - 1) / (8 * (int64_t)PB) + (c->nnodes + PB - 1) / PB) * ntiles;
-        if (items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1) || c->opt_persistent == 2 || c->opt_free_st)
+        if (items >= 2 * 2 * (int64_t)std::max(c->num_cu, 1) || c->opt_persistent == 2 || c->opt_free_st)
             return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     }
     // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
