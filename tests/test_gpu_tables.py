@@ -79,6 +79,25 @@ def test_persistent_kernel_equals_lf_main(st):
     np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=5e-14)
 
 
+def test_persistent_kernel_with_more_walker_tiles_than_workgroup_groups():
+    """B = 600 rows = 75 tiles of 8 walkers for 64 groups of workgroups: a group serves several tiles in turn (the
+    tile_stride loop of lf_free), the last tile ragged."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", 60001, seed=41)
+    ctx = LFContext(inp, max_batch=600)
+    th = _rows(597, 42, wide=True)
+    th[5, 0] = 40.2
+    ctx.set_option("persistent", 0)
+    lp0 = ctx.lnprob_batch(th)
+    ctx.set_option("persistent", 2)
+    lp1 = ctx.lnprob_batch(th)
+    assert ctx.last_launch()["kernel"] == "lf_free<8>" and ctx.last_launch()["rows"] == 597
+    ctx.close()
+    assert np.array_equal(np.isinf(lp1), np.isinf(lp0)) and not np.isnan(lp1).any()
+    fin = np.isfinite(lp0)
+    np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=5e-14)
+
+
 def test_table_form_against_the_oracle():
     from lumfuncmcmc_amd.capi import LFContext
     inp = make_inputs("free", 300007, seed=93)
