@@ -42,7 +42,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
 # sources (profiles/isa_mix.py: FMA = 2 flops, any other fp64 VALU instruction = 1); HOW MANY items took which form
 # in the timed workload comes from the kernel's own census (lf_form_counts).  (The survey's nominal weights - exp/log
 # = 40 flops - would put the same run above peak; DESIGN.md section 4 explains why that figure is not used.)
-SETTLE_STEPS = 20                 # untimed steps after the W warm-up steps, see main()
+SETTLE_STEPS = 20                 # untimed steps after the W warm-up steps, see timed()
+SETTLE_SECONDS = 0.25             # ... and at least this long under load
 SOURCE_FORMS = ("general", "general_noexp", "table", "table_noexp")
 NODE_FORMS = ("node_general", "node_bright")
 # the other variants' grid parts (one or two exponentials per node) and the careful path are left out of `achieved`
@@ -262,21 +263,43 @@ class Leg(object):
             self.ev.close()
 
 
-def timed(leg, fence, warmup, steps, profile_level):
+def fence_light(leg):
+    """Keeps the host from running far ahead of the device during the settle phase (local, no collective)."""
+    import torch
+    torch.cuda.current_stream().synchronize()
+
+
+def timed(leg, fence, warmup, steps, profile_level, agree=None):
     """W warm-up + settle steps, then `steps` timed steps between two fences.  Returns (seconds, kernel times, last out)."""
     import gc
     for i in range(warmup):
         out = leg.step(i)
-    # settle: a few more untimed steps (clocks, caches, allocator pools) after whatever warm-up was asked for
-    for i in range(SETTLE_STEPS):
-        out = leg.step(i)
-    fence()
-    leg.ctx.kernel_times()                      # clear
-    leg.ctx.set_profiling(profile_level)
     # no interpreter pauses inside the timed window: with torch imported a full collection walks ~10^6 objects
     # (40-80 ms, and whether one falls into the window depends on how many objects the flags allocated before)
     gc.collect()
     gc.disable()
+    # settle: more untimed steps after whatever warm-up was asked for, until the device has been under this load for
+    # SETTLE_SECONDS.  The power management of the GPU takes tens of milliseconds of sustained work to reach the
+    # clocks it then holds (tools/time_parts.py: the same launch 127 us in the first 10 ms of load, 112 us after 30 ms);
+    # an MCMC run lasts minutes, so the steady state is the one to quote.  Nothing idles between here and the timed
+    # steps: the fence only waits for the queue to drain.
+    # (Every rank runs the SAME number of steps - they hold collectives: the count comes from a timed first batch and is
+    # agreed by max over the ranks.)
+    t_settle = time.perf_counter()
+    for i in range(SETTLE_STEPS):
+        out = leg.step(i)
+    fence()
+    per_step = (time.perf_counter() - t_settle) / SETTLE_STEPS
+    more = int(min(SETTLE_SECONDS / max(per_step, 1e-6), 20000))
+    if agree is not None:
+        more = int(agree(float(more)))
+    for i in range(more):
+        out = leg.step(i)
+        if i % 64 == 63:
+            fence_light(leg)
+    fence()
+    leg.ctx.kernel_times()                      # clear
+    leg.ctx.set_profiling(profile_level)
     t0 = time.perf_counter()
     dbg = []
     for i in range(steps):
@@ -446,7 +469,7 @@ def main():
 
     leg = Leg(args, model, dev, local, world, rank, Wtot, shard)
     ctx, ndim, half = leg.ctx, leg.ndim, leg.half
-    dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level)
+    dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level, agree=reduce_max)
     dt = reduce_max(dt)
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), "non-finite lnprob in the timed workload"
     step, theta_all, nblk = leg.step, leg.theta_all, leg.nblk
@@ -487,7 +510,7 @@ def main():
                 nst = max(10, args.steps)
                 saved = args.steps
                 args.steps = nst
-                d2, kt2, o2 = timed(lg, fence, 2, nst, 1)
+                d2, kt2, o2 = timed(lg, fence, 2, nst, 1, agree=reduce_max)
                 d2 = reduce_max(d2)
                 if rank == 0:
                     strong[sh] = {"value": W * nst / d2, "unit": "walker-lnprob evals/s", "ms_per_step": d2 / nst * 1e3,

@@ -147,8 +147,10 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * flux-neighbours are narrower than the tables' margins; 0 = always the general form (A/B runs).
  * "persistent": 1 (default) runs the free variant's direct path in lf_free - persistent 512-thread workgroups that
  * hold the g / h tables in LDS, serve one tile of 8 walkers and pull catalogue and grid chunks from per-XCD queues -
- * whenever the catalogue gives every workgroup several items (about N x rows >= 1e8); 0 = always lf_main; 2 = lf_free
- * whenever N >= 32768 (tests).  "free_st": sources per lane of lf_free, 0 (auto = 8), 2, 4 or 8 (tuning runs).
+ * whenever the catalogue and the grid give every workgroup about four items (e.g. N >= 1.8e5 at 128 rows, N = 1e6
+ * from 64 rows); 0 = always lf_main; 2 = always lf_free (tests).  "free_st": sources per lane of lf_free, 0 (auto: 8
+ * for N >= 3e5, else 4), 2, 4 or 8; "node_split": grid items per (node chunk, walker tile), 0 (auto: 2), 1, 2, 4 or 8
+ * (tuning runs).
  * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
  * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
  * Two keys change what is computed, for SOURCE-SHARDED ranks whose lnprob values are summed (all-reduce): "skip_grid" = 1

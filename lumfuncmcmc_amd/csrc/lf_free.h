@@ -29,10 +29,10 @@ constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalo
 
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
 // (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
-__device__ __forceinline__ void reduce_store512(const double* __restrict__ red, int nw, double* __restrict__ out,
+__device__ __forceinline__ void reduce_store512(const double* __restrict__ red, int wlo, int whi, double* __restrict__ out,
                                                 size_t stride, int w0, int chunk, int tid) {
     const int w = tid >> 6, lane = tid & 63;
-    if (w < nw) {
+    if (w >= wlo && w < whi) {             // (wave w sums walker w's 512 lane sums)
         const double* row = red + w * PB + lane;
         double s0 = (row[0] + row[64]) + (row[128] + row[192]);
         double s1 = (row[256] + row[320]) + (row[384] + row[448]);
@@ -44,6 +44,9 @@ __device__ __forceinline__ void reduce_store512(const double* __restrict__ red, 
 struct FreeArgs {
     int B, ntiles;            // theta rows, tiles of PTW walkers
     int nchA, nchB;           // catalogue chunks (512 ST sources), node chunks (512 nodes)
+    int nsplit;               // a node chunk is served in nsplit items of PTW / nsplit walkers each (1, 2 or 4): finer items
+                              // when the catalogue is small and the grid is half of the work
+    int nitB;                 // = nchB * nsplit: grid items per tile (item = sub-tile * nchB + chunk)
     int tile_stride;          // workgroup g serves tiles (g / 8) % ntiles, + tile_stride, ... (normally just one)
     int skip_grid;
     int* queues;              // [ntiles][QSTRIDE]
@@ -99,20 +102,20 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         __builtin_assume(nw >= 1 && nw <= PTW);
         int* __restrict__ q = fa.queues + tile * QSTRIDE;
         // next item of this tile: a node chunk while there are any (item = chunk), then a catalogue chunk of our XCD's
-        // queue, or of the next queue that still has some (item = nchB + chunk); -1 = the tile is done
+        // queue, or of the next queue that still has some (item = nitB + chunk); -1 = the tile is done
         int no_grid = fa.skip_grid;
         asm volatile("" : "+s"(no_grid));                  // (made per tile: kept from the prologue it is the one value spilled)
         auto grab = [&]() -> int {
-            if (!no_grid && fa.nchB > 0) {
+            if (!no_grid && fa.nitB > 0) {
                 const int i = atomicAdd(q, 1);
-                if (i < fa.nchB) return i;
+                if (i < fa.nitB) return i;
             }
             for (int d = 0; d < 8; ++d) {
                 const int qq = (myq + d) & 7;
                 const int lo = (int)(((long long)qq * fa.nchA) >> 3), hi = (int)(((long long)(qq + 1) * fa.nchA) >> 3);
                 if (hi <= lo) continue;
                 const int i = atomicAdd(q + 1 + qq, 1);
-                if (i < hi - lo) return fa.nchB + lo + i;
+                if (i < hi - lo) return fa.nitB + lo + i;
             }
             return -1;
         };
@@ -122,17 +125,17 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         // arrived: one round trip for both.  The result goes to LDS at once: kept in a register across the walker loop
         // it is spilled, and the spill waits for the atomic on the spot.  (build.py keeps the compiler's atomic
         // optimizer from reading the one-lane atomic's result where it is issued.)
-        bool grid_dry = no_grid || fa.nchB <= 0;           // (thread 0's view)
+        bool grid_dry = no_grid || fa.nitB <= 0;           // (thread 0's view)
         int ticket = 0;
         auto take_ticket = [&]() { ticket = atomicAdd(grid_dry ? q + 1 + myq : q, 1); };
         auto redeem = [&]() -> int {
             if (!grid_dry) {
-                if (ticket < fa.nchB) return ticket;
+                if (ticket < fa.nitB) return ticket;
                 grid_dry = true;
                 return grab();
             }
             const int lo = (int)(((long long)myq * fa.nchA) >> 3), hi = (int)(((long long)(myq + 1) * fa.nchA) >> 3);
-            if (ticket < hi - lo) return fa.nchB + lo + ticket;
+            if (ticket < hi - lo) return fa.nitB + lo + ticket;
             return grab();                        // our queue is empty: steal (the grid queue and ours just hand out misses)
         };
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
@@ -184,9 +187,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #endif
             __syncthreads();                      // [D] the previous item's reduction has read `red` (and sitem)
             int t = fresh_tid();
-            if (item >= fa.nchB) {
+            if (item >= fa.nitB) {
                 // ================= catalogue chunk: piece A =================
-                const int c = item - fa.nchB;
+                const int c = item - fa.nitB;
                 // (wave-uniform by construction; said so, or they sit - and are spilled - in vector registers)
                 const int s0 = uni(sa.chunk_start[c]), n = uni(sa.chunk_len[c]), fld = uni(sa.chunk_field[c]);
                 // (kamax: the largest alpha_C key for which THIS WAVE's lanes fit one table piece each)
@@ -325,11 +328,12 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #endif
                 __syncthreads();                  // [C]
                 t = fresh_tid();
-                reduce_store512(red, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
+                reduce_store512(red, 0, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
                 item = sitem[0];
             } else {
                 // ================= node chunk: piece B =================
-                const int c = item;
+                const int sub = item / fa.nchB, c = item - sub * fa.nchB;                          // walker sub-tile, chunk
+                const int wlo = sub * (PTW / fa.nsplit), whi = min(wlo + PTW / fa.nsplit, nw);     // (empty for a ragged last tile)
                 const bool valid = c * PB + t < na.nnodes;
                 const int g = min(c * PB + t, na.nnodes - 1);
                 if (t == 0) take_ticket();        // in front of the loads: back when they are
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 if (t == 0) sitem[0] = redeem();
                 const int nodes_here = min(PB, na.nnodes - c * PB);
 #pragma unroll 1
-                for (int w = 0; w < nw; ++w) {
+                for (int w = wlo; w < whi; ++w) {
                     const double* __restrict__ sc = wsc + w * 8;
                     const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (w * MAXF) * 8 + 4));
                     double val = 0.0;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 }
                 __syncthreads();                  // [C]
                 t = fresh_tid();
-                reduce_store512(red, nw, fa.partB, (size_t)fa.nchB, w0, c, t);
+                reduce_store512(red, wlo, whi, fa.partB, (size_t)fa.nchB, w0, c, t);
                 item = sitem[0];
             }
 #ifdef LF_STAMPS

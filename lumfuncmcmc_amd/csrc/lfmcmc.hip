@@ -70,6 +70,7 @@ struct lf_ctx {
     std::map<int, ChunkTable> chunks_free;   // the persistent FREE kernel's (lf_free.h): 512 ST sources per chunk, lanes of ST
     int64_t opt_persistent = 1;         // FREE: 1 = lf_free (persistent 512-thread workgroups) for catalogues that fill it
     int64_t opt_free_st = 0;            // lf_free: sources per lane, 0 = chosen from N and B, else 2 / 4 / 8 (tuning runs)
+    int64_t opt_node_split = 0;         // lf_free: grid items per node chunk and walker tile, 0 = chosen, else 1 / 2 / 4 / 8
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     int64_t opt_taper = 0;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers (second pass over the catalogue)
@@ -389,6 +390,25 @@ void launch_main(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int t
 
 // FREE variant, real catalogue, catalogues large enough to fill it: prepare -> lf_free (persistent 512-thread workgroups,
 // pieces A and B, lf_free.h) -> finalize
+// Item sizes of the persistent FREE kernel (lf_free.h).  Sources per lane: 8 (the table lookup is shared by 8 terms)
+// once the catalogue gives 4096-source chunks enough to go round, else 4; a node chunk is served in two items of four
+// walkers each (measured on a warmed-up device, 128 rows, us: N = 1e6 113.4 -> 111.6, 5e5 74.4 -> 72.4 with ST = 8;
+// N = 2.5e5 58.1 -> 55.7, 1e5 45.7 -> 40.2 going from ST = 8 to 4).  free_st / node_split override (tuning runs).
+struct FreeShape {
+    int st, nsplit;
+    int64_t items_per_tile;      // catalogue chunks + grid items
+};
+FreeShape free_shape(const lf_ctx* c) {
+    using namespace lf;
+    FreeShape fs;
+    const int64_t chunks8 = (c->N + 8 * (int64_t)PB - 1) / (8 * (int64_t)PB);
+    fs.st = c->opt_free_st ? (int)c->opt_free_st : (chunks8 >= 74 ? 8 : 4);
+    fs.nsplit = c->opt_node_split ? (int)c->opt_node_split : 2;
+    const int64_t nchB = c->opt_skip_grid ? 0 : (c->nnodes + PB - 1) / PB;
+    fs.items_per_tile = (c->N + (int64_t)PB * fs.st - 1) / ((int64_t)PB * fs.st) + nchB * fs.nsplit;
+    return fs;
+}
+
 template <int ST>
 void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa, const lf::NodeArrays& na, lf::FreeArgs fa, hipStream_t s) {
     using namespace lf;
@@ -404,7 +424,7 @@ void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa
     }
     // groups of 8 workgroups (one per XCD under round-robin placement) per tile; no more than the chip holds at once,
     // no more than there are items
-    const int64_t per_tile = ((int64_t)fa.nchA + fa.nchB + 7) / 8;
+    const int64_t per_tile = ((int64_t)fa.nchA + fa.nitB + 7) / 8;
     const int64_t g8 = std::max<int64_t>(1, std::min<int64_t>(c->slots_free[slot] / 8, (int64_t)ntiles * std::max<int64_t>(per_tile, 1)));
     fa.tile_stride = (int)g8;
     const dim3 grid((unsigned)(8 * g8));
@@ -418,22 +438,14 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
                  const lf::StepArgs& sp, const lf::AcceptArgs& ap) {
     using namespace lf;
     const int ntiles = (B + PTW - 1) / PTW;
-    // sources per lane: 8 when that still leaves every workgroup a few items, else 4, else 2
-    const int slots = c->slots_free[2] ? c->slots_free[2] : 2 * std::max(c->num_cu, 1);
-    int st = 2, slot = 0;
-    for (int cand = 8, sl = 2; cand >= 2; cand /= 2, --sl) {
-        const int64_t chunks = (c->N + (int64_t)PB * cand - 1) / ((int64_t)PB * cand);
-        if (c->opt_free_st ? cand == c->opt_free_st : (cand == 8 || chunks * ntiles >= 2 * (int64_t)slots || cand == 2)) {
-            st = cand;
-            slot = sl;
-            break;
-        }
-    }
+    const FreeShape fs = free_shape(c);
+    const int st = fs.st, slot = fs.st == 8 ? 2 : (fs.st == 4 ? 1 : 0);
     ChunkTable* ct = nullptr;
     int rc = get_chunks(c, c->chunks_free, c->field_ind, PB * st, &ct, c->h_x.data(), st);
     if (rc != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + PB - 1) / PB;
+    const int nsplit = fs.nsplit;
     rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1));
     if (rc != LF_OK) return rc;
     if (ntiles * QSTRIDE > c->cap_queue) {
@@ -454,7 +466,7 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     }
     const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
     const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
-    FreeArgs fa{B, ntiles, nchA, nchB, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB};
+    FreeArgs fa{B, ntiles, nchA, nchB, nsplit, nchB * nsplit, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB};
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
@@ -483,14 +495,14 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     // geometry of lf_main was asked for explicitly
     if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
         !(c->opt_compress && c->cmp.built) && (c->N >= 32768 || c->opt_persistent == 2)) {
-        // Measured crossover (B = 128: lf_main 42 / 48 / 55 / 68 / 110 / 167 us at N = 1e5 / 1.25e5 / 1.8e5 / 2.5e5 / 5e5 /
-        // 1e6, lf_free 60 / 51 / 52 / 57 / 78 / 122; B = 256 at N = 1.25e5: 78 against 69): the persistent kernel wins once
-        // every one of its ~512 workgroups gets about two items or more (items = 4096-source chunks and 512-node chunks
-        // per tile of 8 walkers; N >~ 1.8e5 at 128 rows); below that its coarse items cost more than its tables save.
-        // opt_persistent = 2 or an explicit free_st force it (tests, tuning runs).
+        // Measured crossover (tools/time_parts.py on a warmed-up device, lf_main / lf_free in us; 128 rows: N = 5e4 33 / 37,
+        // 7e4 36 / 38, 1e5 40 / 40, 1.8e5 49 / 49, 2.5e5 60 / 56, 5e5 95 / 72, 1e6 168 / 112; N = 1e6 with 16 / 32 / 64 /
+        // 256 rows: 29 / 79, 50 / 56, 91 / 72, 327 / 205; N = 1e5 with 512 rows: 127 / 120): the persistent kernel wins
+        // once every one of its ~512 workgroups gets about four items or more; below that its coarse items cost more
+        // than its tables save.  opt_persistent = 2 or an explicit free_st force it (tests, tuning runs).
         const int64_t ntiles = (B + PTW - 1) / PTW;
-        const int64_t items = ((c->N + 8 * (int64_t)PB - 1) / (8 * (int64_t)PB) + (c->nnodes + PB - 1) / PB) * ntiles;
-        if (items >= 2 * 2 * (int64_t)std::max(c->num_cu, 1) || c->opt_persistent == 2 || c->opt_free_st)
+        const int64_t items = free_shape(c).items_per_tile * ntiles;
+        if (items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1) || c->opt_persistent == 2 || c->opt_free_st)
             return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     }
     // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
@@ -1349,6 +1361,14 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             return LF_ERR_ARG;
         }
         c->opt_free_st = value;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "node_split") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) {
+            c->err = "node_split must be 0 (auto), 1, 2, 4 or 8";
+            return LF_ERR_ARG;
+        }
+        c->opt_node_split = value;
         return LF_OK;
     }
     if (std::strcmp(key, "persistent") == 0) {

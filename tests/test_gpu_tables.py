@@ -91,7 +91,7 @@ def test_persistent_kernel_with_more_walker_tiles_than_workgroup_groups():
     lp0 = ctx.lnprob_batch(th)
     ctx.set_option("persistent", 2)
     lp1 = ctx.lnprob_batch(th)
-    assert ctx.last_launch()["kernel"] == "lf_free<8>" and ctx.last_launch()["rows"] == 597
+    assert ctx.last_launch()["kernel"].startswith("lf_free") and ctx.last_launch()["rows"] == 597
     ctx.close()
     assert np.array_equal(np.isinf(lp1), np.isinf(lp0)) and not np.isnan(lp1).any()
     fin = np.isfinite(lp0)

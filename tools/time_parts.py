@@ -30,6 +30,14 @@ def main():
     th = [torch.from_numpy(synth.walkers(a.variant, a.rows, seed=s)).cuda() for s in (1, 2, 3, 4)]
     st = torch.cuda.Stream()
     torch.cuda.set_stream(st)
+    # the GPU's clocks take tens of milliseconds of sustained load to settle (the same launch: 127 us in the first 10 ms,
+    # 112 us after 30 ms): load it first, or the order of the sets decides the comparison
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.4:
+        for i in range(16):
+            ctx.lnprob_torch(th[i % 4])
+        torch.cuda.synchronize()
     for spec in a.sets.split(";"):
         opts = [] if spec == "default" else [kv.split("=") for kv in spec.split(",")]
         for k, v in opts:
