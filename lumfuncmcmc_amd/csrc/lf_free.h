@@ -47,6 +47,7 @@ struct FreeArgs {
     int nsplit;               // a node chunk is served in nsplit items of PTW / nsplit walkers each (1, 2 or 4): finer items
                               // when the catalogue is small and the grid is half of the work
     int nitB;                 // = nchB * nsplit: grid items per tile (item = sub-tile * nchB + chunk)
+    int wpn;                  // = PTW / nsplit: walkers per grid item
     int tile_stride;          // workgroup g serves tiles (g / 8) % ntiles, + tile_stride, ... (normally just one)
     int skip_grid;
     int* queues;              // [ntiles][QSTRIDE]
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #endif
             __syncthreads();                      // [D] the previous item's reduction has read `red` (and sitem)
             int t = fresh_tid();
-            if (item >= fa.nitB) {
+            if (__builtin_expect(item >= fa.nitB, 1)) {
                 // ================= catalogue chunk: piece A =================
                 const int c = item - fa.nitB;
                 // (wave-uniform by construction; said so, or they sit - and are spilled - in vector registers)
@@ -332,8 +333,12 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 item = sitem[0];
             } else {
                 // ================= node chunk: piece B =================
-                const int sub = item / fa.nchB, c = item - sub * fa.nchB;                          // walker sub-tile, chunk
-                const int wlo = sub * (PTW / fa.nsplit), whi = min(wlo + PTW / fa.nsplit, nw);     // (empty for a ragged last tile)
+                int sub = 0, c = item;                                                             // walker sub-tile, chunk
+                while (c >= fa.nchB) {            // (item = sub * nchB + c with sub < nsplit <= 8: a few scalar subtractions; a
+                    c -= fa.nchB;                 // division by a run-time value leaves a reciprocal to be hoisted and spilled)
+                    ++sub;
+                }
+                const int wlo = sub * fa.wpn, whi = min(wlo + fa.wpn, nw);                         // (empty for a ragged last tile)
                 const bool valid = c * PB + t < na.nnodes;
                 const int g = min(c * PB + t, na.nnodes - 1);
                 if (t == 0) take_ticket();        // in front of the loads: back when they are

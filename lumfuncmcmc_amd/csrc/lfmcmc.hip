@@ -466,7 +466,7 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     }
     const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
     const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
-    FreeArgs fa{B, ntiles, nchA, nchB, nsplit, nchB * nsplit, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB};
+    FreeArgs fa{B, ntiles, nchA, nchB, nsplit, nchB * nsplit, PTW / nsplit, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB};
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
