@@ -304,6 +304,13 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
             r[Z_AP] = aP; r[Z_BP] = bP; r[Z_CP] = cP;
             r[Z_C1] = c1;
         }
+        if (live && has_f) {
+            // the local form of the term (srcsum_body) expands L*(z) about a lane's middle source: the size of its
+            // exponent is bounded by this slope times the lane's width in z (a lane is narrower than 1 / 128 or the
+            // chunk's key is 0 and the form is not taken)
+            const double s0 = fabs(fma(2.0 * aL, kc.z_lo[f], bL)), s1 = fabs(fma(2.0 * aL, kc.z_hi[f], bL));
+            r[RF(f, 0)] = LF_LN10 * (fmax(s0, s1) + fabs(aL) * (1.0 / 128.0));
+        }
         if (has_f && kc.nsrc[f] > 0) {
             double lsmn, lsmx, phmn, phmx;
             quad_range(aL, bL, cL, kc.z_lo[f], kc.z_hi[f], lsmn, lsmx);
@@ -480,6 +487,7 @@ __device__ __forceinline__ double term_free_careful(const WFree& w, double lum, 
 
 struct WZ {
     double aL, bL, cL, aP, bP, cP, c1;
+    double mslope;     // ln10 * (max |dL*/dz| over the field's redshifts + |aL| / 128): bounds the exponent of the local form
 };
 
 template <bool FAST>
@@ -572,16 +580,20 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             return;
         }
     }
+    // ZEVOL on the real catalogue: a lane holds ST NEIGHBOURS in redshift (the catalogue is sorted by z inside a field),
+    // not every 256th source - see the local form of the term below.  Any assignment of sources to lanes gives the same
+    // sums up to rounding; the careful loop further down re-reads by index and covers every source once either way.
+    constexpr bool ZLOCAL = VARIANT == LF_ZEVOL && !CMP;
     // items -> registers (lanes past the end replay the chunk's first source with weight 0)
     double lum[ST], a1[ST], pp[ST], uu[ST], wgt[ST];
 #pragma unroll
     for (int k = 0; k < ST; ++k) {
-        const int i = k * BLOCK + tid;
+        const int i = ZLOCAL ? tid * ST + k : k * BLOCK + tid;
         const size_t g = (size_t)s0 + (i < n ? i : 0);
         wgt[k] = i < n ? (CMP ? sa.W[g] : 1.0) : 0.0;
         lum[k] = sa.lum[g];
         a1[k] = sa.a1[g];
-        pp[k] = sa.P[g];
+        pp[k] = ZLOCAL ? 0.0 : sa.P[g];
         uu[k] = VARIANT == LF_FIXCOMP ? 0.0 : sa.U[g];
         if (VARIANT == LF_FREE && i >= n) {
             // padding lanes of the FAST loop: a source so bright that fc = 1 and the decay is 1, i.e.
@@ -589,6 +601,25 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             a1[k] = 1.0e30;
             uu[k] = 1.0e4;
         }
+    }
+    // ZEVOL, local form: with z_c the lane's first source and d_k = z_k - z_c (L* is a quadratic: the expansion is exact),
+    //     10^(lum_k - L*(z_k)) = 10^(42 - L*(z_c)) * 10^(lum_k - 42) * exp(e_k),   e_k = -ln10 (L*'(z_c) + aL d_k) d_k
+    // - ONE exponential per (walker, lane) instead of one per (walker, source): the lane's sources are neighbours in z,
+    // so e_k is tiny and exp(e_k) is a degree-5 polynomial (1e-16 for |e_k| <= 6e-3).  10^(lum_k - 42) does not depend
+    // on the walker and is made here, once per item (in the registers of ln Om, which this path does not read).
+    // Measured against the per-source form on 4e5 sources, walkers over the whole prior box, three pivot sets: 2-3e-16
+    // on piece A, the same 6e-16 .. 8e-15 from the oracle as the per-source form.  Whether |e_k| <= 6e-3 holds for a
+    // (walker, chunk) pair is one compare: the walker's bound on ln10 |dL*/dz| over the field (lf_prepare) times the
+    // chunk's widest lane, which get_chunks folded into the chunk's third key (kamax = floor(2^16 G_MARGIN / width),
+    // 0 if the width exceeds 1 / 128 or is unknown).  Pairs that fail take the per-source exponential as before.
+    double zc = 0.0, zwidth_inv = 0.0;
+    if (ZLOCAL) {
+        zc = a1[0];          // (the lane's first source: real whenever any of the lane's sources is - a ragged chunk's pads replay
+                             // the chunk's first source, which is not a neighbour)
+#pragma unroll
+        for (int k = 0; k < ST; ++k) pp[k] = wgt[k] * fexp_t(LF_LN10 * (lum[k] - LF_LREF), &tab);
+        const int kamax = sa.chunk_keys ? __builtin_amdgcn_readfirstlane(sa.chunk_keys[KEY_STRIDE * c + 2]) : 0;
+        zwidth_inv = (double)kamax * (1.0 / (G_MARGIN * KEY_ASCALE));      // <= 1 / (widest lane); 0: unknown
     }
     const double NEG_INF = -__builtin_huge_val();
     // walker constants (and the walker's mode) of the NEXT walker are fetched with scalar loads while the
@@ -604,7 +635,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             nxC = r0[RF(fld, F_CA)];
             nxV = r0[RF(fld, F_V)];
         }
-        if (VARIANT == LF_ZEVOL) nz = WZ{r0[Z_AL], r0[Z_BL], r0[Z_CL], r0[Z_AP], r0[Z_BP], r0[Z_CP], r0[Z_C1]};
+        if (VARIANT == LF_ZEVOL) nz = WZ{r0[Z_AL], r0[Z_BL], r0[Z_CL], r0[Z_AP], r0[Z_BP], r0[Z_CP], r0[Z_C1], r0[RF(fld, 0)]};
     }
 #pragma unroll 1
     for (int w = 0; w < nw; ++w) {
@@ -647,9 +678,30 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 // nothing left per source: piece A is the closed form in wbase
             } else {
                 const WZ wz = nz;
-                nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
+                nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1], rn[RF(fld, 0)]};
                 if (mode < MODE_SKIP) {
-                if (!CMP) asm volatile("; LF_BEGIN zevol items=%0" ::"n"(ST));
+                if (ZLOCAL && kc.specialise && wz.mslope <= 6.0e-3 * zwidth_inv) {      // (wave-uniform)
+                    asm volatile("; LF_BEGIN zevol items=%0" ::"n"(ST));
+                    const double Lc = quad_nofma(wz.aL, wz.bL, wz.cL, zc, uu[0]);
+                    const double Hc = fexp_t(LF_LN10 * (LF_LREF - Lc), &tab);
+                    const double a2 = -LF_LN10 * wz.aL;
+                    const double s1 = fma(2.0 * a2, zc, -LF_LN10 * wz.bL);          // -ln10 L*'(z_c)
+                    double sum4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int k = 0; k < ST; ++k) {
+                        const double dz = a1[k] - zc;
+                        const double e = fma(a2, dz, s1) * dz;
+                        double p = fma(e, 1.0 / 120.0, 1.0 / 24.0);
+                        p = fma(p, e, 1.0 / 6.0);
+                        p = fma(p, e, 0.5);
+                        p = fma(p, e, 1.0);
+                        p = fma(p, e, 1.0);
+                        sum4[k & 3] = k < 4 ? pp[k] * p : fma(pp[k], p, sum4[k & 3]);
+                    }
+                    acc = -Hc * ((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));      // everything else of the term is in wbase
+                    asm volatile("; LF_END zevol");
+                } else {
+                if (!CMP) asm volatile("; LF_BEGIN zevol_direct items=%0" ::"n"(ST));
 #pragma unroll
                 for (int k = 0; k < ST; ++k) {
                     const double Ls = CMP ? quad_comp(wz.aL, wz.bL, wz.cL, a1[k])
@@ -659,7 +711,8 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                     const double v = fexp_t(LF_LN10 * (lum[k] - Ls), &tab);
                     acc = fma(-v, wgt[k], acc);             // everything else of the term is in wbase
                 }
-                if (!CMP) asm volatile("; LF_END zevol");
+                if (!CMP) asm volatile("; LF_END zevol_direct");
+                }
                 }
             }
         } else if (CMP) {
@@ -669,7 +722,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 nxC = rn[RF(fld, F_CA)];
                 nxV = rn[RF(fld, F_V)];
             }
-            if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
+            if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1], rn[RF(fld, 0)]};
         } else {
             // careful path (rare): device-library math, per-term underflow checks, -inf poisoning.  Items
             // are re-read from memory inside a rolled loop so that this path adds no register pressure
@@ -680,7 +733,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 nxC = rn[RF(fld, F_CA)];
                 nxV = rn[RF(fld, F_V)];
             }
-            if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1]};
+            if (VARIANT == LF_ZEVOL) nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1], rn[RF(fld, 0)]};
 #pragma unroll 1
             for (int k = 0; k < ST; ++k) {
                 const int i = k * BLOCK + tid;
@@ -699,7 +752,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                     const bool bad = (v > LF_UNDERFLOW) | (lnT < -LF_UNDERFLOW) | (term < -LF_UNDERFLOW) | (term != term);
                     term = bad ? NEG_INF : 0.0;             // the value itself is in wbase
                 } else {
-                    const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
+                    const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1], 0.0};
                     double v;
                     const double lnT = lnT_zevol<false>(wz, clum, ca1, sa.U[g], v, &tab);
                     term = lnT + cpp;
@@ -963,7 +1016,7 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
         } else if (VARIANT == LF_FIXCOMP) {
             val = W * fexp_c(fma(r[R_C1], G - r[R_LSTAR], r[R_C0]) - PG * r[R_Q], &tab);
         } else {
-            const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1]};
+            const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1], 0.0};
             double v;
             val = W * fexp_c(lnT_zevol<true>(wz, G, a3, a4, v, &tab), &tab);
         }

@@ -515,10 +515,13 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     }
     const Geo geo = GEOS[gi];
     ChunkTable *ct = nullptr, *ctd = nullptr;
+    // (ZEVOL, real catalogue: the chunk keys carry the widest lane of z-neighbours, lane = geo.st consecutive sources -
+    // what the local form of the term needs to know, lf_kernels.h: srcsum_body)
+    const double* hz = c->kc.variant == LF_ZEVOL && !c->h_x.empty() ? c->h_x.data() : nullptr;
     int rc = cmp ? get_chunks(c, c->cmp.chunks, c->cmp.field_ind, geo.st * BLOCK, &ct)
-                 : get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ct);
+                 : get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ct, hz, hz ? geo.st : 0);
     if (rc != LF_OK) return rc;
-    if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd)) != LF_OK) return rc;
+    if (cmp && (rc = get_chunks(c, c->chunks, c->field_ind, geo.st * BLOCK, &ctd, hz, hz ? geo.st : 0)) != LF_OK) return rc;
     const int nchA = ct->n;
     const int nchD = cmp ? ctd->n : 0;
     // rescue workgroups leave at once unless a walker was flagged; still, each costs a dispatch slot: scale with B
@@ -893,12 +896,16 @@ int build(lf_ctx* c, const lf_desc* d) {
     // a cheaper form of the term per (walker, chunk) - see term_free_noexp.  NaN fluxes go last.
     std::vector<int64_t> perm((size_t)N);
     for (int64_t i = 0; i < N; ++i) perm[(size_t)i] = i;
-    if (d->variant == LF_FREE)
+    // ZEVOL: in order of redshift, so that a lane's ST sources are neighbours in z and 10^(-L*(z)) of all of them follows
+    // from ONE exponential at the lane's middle source (lf_kernels.h: the local form of the z-evolving term).
+    if (d->variant == LF_FREE || d->variant == LF_ZEVOL) {
+        const double* key = d->variant == LF_FREE ? d->logf : d->z;
         for (int f = 0; f < nf; ++f)
             std::stable_sort(perm.begin() + d->field_ind[f], perm.begin() + d->field_ind[f + 1], [&](int64_t a, int64_t b) {
-                const double x = d->logf[a], y = d->logf[b];
+                const double x = key[a], y = key[b];
                 return std::isnan(y) ? !std::isnan(x) : x < y;
             });
+    }
     std::vector<double> lumv(N), a1(N), P(N), U(N);
     for (int64_t i = 0; i < N; ++i) lumv[(size_t)i] = d->lum[perm[(size_t)i]];
     for (int64_t i = 0; i < N; ++i) {
@@ -968,8 +975,9 @@ int build(lf_ctx* c, const lf_desc* d) {
         kc.sz[f] = (double)sz;
         kc.sz2[f] = (double)sz2;
     }
-    if (d->variant == LF_FREE) {
-        // origin of the integer keys of log-flux, and the host copy of the sorted fluxes the chunk keys come from
+    if (d->variant == LF_FREE || d->variant == LF_ZEVOL) {
+        // origin of the integer keys of log-flux (ZEVOL: of redshift), and the host copy of the sorted values the chunk
+        // keys come from
         double x0 = HUGE_VAL;
         for (int64_t i = 0; i < N; ++i)
             if (std::isfinite(a1[(size_t)i])) x0 = std::fmin(x0, a1[(size_t)i]);

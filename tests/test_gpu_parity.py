@@ -334,3 +334,33 @@ def test_end_to_end_against_the_reference_at_baseline_sizes(name):
     print("%s worst rel %.2e (%d rows -inf)" % (name, worst, ninf))
     assert ninf >= 4
     o.close()
+
+
+@pytest.mark.parametrize("n,nf,zslices,pivots", [(400000, 5, 8, (1.20, 1.53, 1.86)), (250001, 3, 0, (1.18, 1.36, 1.54)),
+                                                 (33333, 4, 0, (1.20, 1.76, 2.32))])
+def test_zevol_local_form_equals_the_per_source_form(n, nf, zslices, pivots):
+    """The z-evolving term with ONE exponential per (walker, lane of z-neighbours) (lf_kernels.h: srcsum_body, local
+    form) against the per-source exponential of the same kernel ("specialise" = 0) and against the oracle: walkers over
+    the whole prior box of L1..L3 (steep, curved L*(z)), ragged last chunks and lanes (n is not a multiple of anything),
+    a catalogue small enough that wide lanes send some walkers back to the per-source form."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("zevol", n, seed=31, nf=nf, zslices=zslices, pivots=pivots)
+    th = synth.walkers("zevol", 40, seed=32, nf=nf)
+    rng = np.random.default_rng(33)
+    th[8:, 0:3] = rng.uniform(41.2, 44.8, (32, 3))
+    ref = O.lnprob_batch(inp, th[:10])
+    ctx = LFContext(inp)
+    a1, b1 = ctx.lnprob_pieces(th)
+    lp1 = ctx.lnprob_batch(th)
+    ctx.set_option("specialise", 0)
+    a0, b0 = ctx.lnprob_pieces(th)
+    lp0 = ctx.lnprob_batch(th)
+    ctx.close()
+    assert np.array_equal(np.isinf(lp1), np.isinf(lp0)) and not np.isnan(lp1).any()
+    fin = np.isfinite(lp0)
+    np.testing.assert_allclose(a1[fin], a0[fin], rtol=2e-15)
+    np.testing.assert_array_equal(b1[fin], b0[fin])
+    f10 = np.isfinite(ref)
+    np.testing.assert_allclose(lp1[:10][f10], ref[f10], rtol=RTOL)
+    if n == 400000:
+        assert not np.array_equal(a1[fin], a0[fin])          # (the local form did run: only FAST-mode walkers take it)
