@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
 # = 40 flops - would put the same run above peak; DESIGN.md section 4 explains why that figure is not used.)
 SETTLE_STEPS = 20                 # untimed steps after the W warm-up steps, see timed()
 SETTLE_SECONDS = 0.25             # ... and at least this long under load
-SOURCE_FORMS = ("general", "general_noexp", "table", "table_noexp")
+SOURCE_FORMS = ("general", "general_noexp", "table", "table_noexp", "cell")      # ("cell": per (walker, cell), not per source)
 NODE_FORMS = ("node_general", "node_bright")
 # the other variants' grid parts (one or two exponentials per node) and the careful path are left out of `achieved`
 # bytes the per-source loop streams per source and launch: logf_i and U_i = 10^(logf_i + 17) (free: the
@@ -355,6 +355,9 @@ def roofline_of(args, leg, model, kt, dt):
         grid_flops = grid_cycles = 0.0
     alg_flops = src_flops + grid_flops
     alg_bytes = nsrc * BYTES_PER_SOURCE[variant] + rows * 8 * (leg.ndim + 1)
+    if cnt.get("cell", 0.0) > 0.0 and cnt.get("table", 0.0) + cnt.get("general", 0.0) == 0.0:
+        # every walker was summed over the catalogue's cells: 64 B per cell are streamed, not the sources
+        alg_bytes = cnt["cell"] / max(rows, 1) * 64 + rows * 8 * (leg.ndim + 1)
     traffic = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf) and leg.world == 1:

@@ -150,7 +150,11 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * whenever the catalogue and the grid give every workgroup about four items (e.g. N >= 1.8e5 at 128 rows, N = 1e6
  * from 64 rows); 0 = always lf_main; 2 = always lf_free (tests).  "free_st": sources per lane of lf_free, 0 (auto: 8
  * for N >= 3e5, else 4), 2, 4 or 8; "node_split": grid items per (node chunk, walker tile), 0 (auto: 2), 1, 2, 4 or 8
- * (tuning runs).
+ * (tuning runs).  "cells": 1 (default) lets lf_free sum a walker whose every field lies inside the tables over the
+ * catalogue's CELLS instead of its sources: runs of flux-neighbouring sources no wider than 2 rho, kept as their
+ * midpoint and power sums S_0 .. S_6; on a table piece the term is a polynomial in the flux offset, so a cell's sum is
+ * a dot product of its Taylor coefficients with the power sums, exact up to the orders above 6, whose share is below
+ * 3e-17 by the choice of rho (from the prior box's largest alpha_C).  0 = every walker over the sources (A/B runs).
  * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
  * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
  * Two keys change what is computed, for SOURCE-SHARDED ranks whose lnprob values are summed (all-reduce): "skip_grid" = 1
@@ -160,12 +164,13 @@ int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
 
 /* Census of which form of the per-source term / grid node ran since lf_set_option(ctx, "count_forms", 1) (which also
  * clears it; 0 switches it off again - it costs one atomic per (walker, chunk), so it is off by default).  For
- * bench.py's executed-flop accounting and the tests.  counts[0..7] = (walker, source) terms evaluated in the general
+ * bench.py's executed-flop accounting and the tests.  counts[0..8] = (walker, source) terms evaluated in the general
  * form, the general form without the exponential, the table-driven form, the table-driven form without the
  * exponential, the careful (checked) form, terms of walkers that were not evaluated (outside the prior / already
- * -inf); then (walker, node, field) terms of the grid integral in the general and in the bright form.  FREE variant,
+ * -inf); then (walker, node, field) terms of the grid integral in the general and in the bright form; then
+ * (walker, cell) evaluations (option "cells": a cell stands for all the sources of a narrow flux interval).  FREE variant,
  * real catalogue (the other variants and the compressed catalogue leave it at 0).  Synchronises the device. */
-int lf_form_counts(lf_ctx *ctx, int64_t counts[8]);
+int lf_form_counts(lf_ctx *ctx, int64_t counts[9]);
 
 /* Shape of the most recent lf_main launch of this context (measurement only): info[0..7] = sources per lane, walkers
  * per source workgroup and per grid workgroup of the instantiation (template parameters ST, TW, TWB); which kernel ran

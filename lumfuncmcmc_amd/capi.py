@@ -347,11 +347,11 @@ class LFContext(object):
         names = ("prepare", "main", "unused", "finalize")
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(names)}
 
-    FORM_NAMES = ("general", "general_noexp", "table", "table_noexp", "careful", "skipped", "node_general", "node_bright")
+    FORM_NAMES = ("general", "general_noexp", "table", "table_noexp", "careful", "skipped", "node_general", "node_bright", "cell")
 
     def form_counts(self):
         """Census of the term forms since set_option("count_forms", 1): dict name -> count (include/lfmcmc.h)."""
-        n = (ctypes.c_int64 * 8)()
+        n = (ctypes.c_int64 * 9)()
         self._check(self._lib.lf_form_counts(self._h, n))
         return {k: int(n[i]) for i, k in enumerate(self.FORM_NAMES)}
 

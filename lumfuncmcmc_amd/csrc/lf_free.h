@@ -53,6 +53,14 @@ struct FreeArgs {
     int* queues;              // [ntiles][QSTRIDE]
     double* partA;            // [B][nchA]
     double* partB;            // [B][nchB]
+    // cells (lf_kernels.h: CELL_M): walkers flagged STAT_CELLS by lf_prepare are summed over them instead of the sources
+    const double* cells;      // [ncell][8] {x_c, S_0 .. S_6}
+    const int* cc_start;      // [nchC] first cell of a cell chunk
+    const int* cc_len;        // [nchC] its cells (<= 512: one per lane)
+    const int* cc_field;      // [nchC]
+    int nchC;                 // cell chunks: items nitB .. nitB + nchC - 1 of the tile's front queue (0: no cells)
+    double* partC;            // [B][nchC]
+    const int* wstat;         // [B]
 };
 
 // CENSUS: the instantiation that counts which form of the term ran (lf_form_counts); the product one has no trace of it
@@ -65,6 +73,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
     __shared__ __attribute__((aligned(16))) double wfc[PTW * MAXF * 8];   // per (walker, field): aC, V, cA, cYs, {mode, klo, khi, kne, kaC}, cYH
     __shared__ __attribute__((aligned(16))) double wsc[PTW * 8];          // per walker: L*, c0, c1, Q, alpha_C
     __shared__ int sitem[2];
+    __shared__ int scell;                  // bit w: walker w of the tile is summed over the cells
     const int tid = threadIdx.x;
     // ---- once per workgroup: the tables, and which XCD we are on
     for (int i = tid; i < 256; i += PB) {
@@ -104,19 +113,20 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         int* __restrict__ q = fa.queues + tile * QSTRIDE;
         // next item of this tile: a node chunk while there are any (item = chunk), then a catalogue chunk of our XCD's
         // queue, or of the next queue that still has some (item = nitB + chunk); -1 = the tile is done
-        int no_grid = fa.skip_grid;
-        asm volatile("" : "+s"(no_grid));                  // (made per tile: kept from the prologue it is the one value spilled)
+        const int nF = fa.nitB + fa.nchC;          // front queue: grid items, then cell chunks
+        bool no_src = false;                       // (thread 0's view) every walker of the tile is summed over the cells
         auto grab = [&]() -> int {
-            if (!no_grid && fa.nitB > 0) {
+            if (nF > 0) {
                 const int i = atomicAdd(q, 1);
-                if (i < fa.nitB) return i;
+                if (i < nF) return i;
             }
+            if (no_src) return -1;
             for (int d = 0; d < 8; ++d) {
                 const int qq = (myq + d) & 7;
                 const int lo = (int)(((long long)qq * fa.nchA) >> 3), hi = (int)(((long long)(qq + 1) * fa.nchA) >> 3);
                 if (hi <= lo) continue;
                 const int i = atomicAdd(q + 1 + qq, 1);
-                if (i < hi - lo) return fa.nitB + lo + i;
+                if (i < hi - lo) return nF + lo + i;
             }
             return -1;
         };
@@ -126,22 +136,33 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         // arrived: one round trip for both.  The result goes to LDS at once: kept in a register across the walker loop
         // it is spilled, and the spill waits for the atomic on the spot.  (build.py keeps the compiler's atomic
         // optimizer from reading the one-lane atomic's result where it is issued.)
-        bool grid_dry = no_grid || fa.nitB <= 0;           // (thread 0's view)
+        bool grid_dry = nF <= 0;                           // (thread 0's view)
         int ticket = 0;
-        auto take_ticket = [&]() { ticket = atomicAdd(grid_dry ? q + 1 + myq : q, 1); };
+        auto take_ticket = [&]() {
+            if (!(grid_dry && no_src)) ticket = atomicAdd(grid_dry ? q + 1 + myq : q, 1);
+        };
         auto redeem = [&]() -> int {
             if (!grid_dry) {
-                if (ticket < fa.nitB) return ticket;
+                if (ticket < nF) return ticket;
                 grid_dry = true;
                 return grab();
             }
+            if (no_src) return -1;
             const int lo = (int)(((long long)myq * fa.nchA) >> 3), hi = (int)(((long long)(myq + 1) * fa.nchA) >> 3);
-            if (ticket < hi - lo) return fa.nitB + lo + ticket;
+            if (ticket < hi - lo) return nF + lo + ticket;
             return grab();                        // our queue is empty: steal (the grid queue and ours just hand out misses)
         };
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
         const int u = fresh_tid();
-        if (u == 0) sitem[0] = grab();
+        if (u == 0) {
+            // which walkers of the tile lf_prepare put on the cells; when all of them are, the sources are not touched
+            int m = 0;
+            if (fa.nchC > 0)
+                for (int w = 0; w < nw; ++w) m |= (fa.wstat[w0 + w] & STAT_CELLS) ? 1 << w : 0;
+            scell = m;
+            no_src = fa.nchC > 0 && m == (1 << nw) - 1;
+            sitem[0] = grab();
+        }
         // the tile's walker constants, all fields (64 B per (walker, field)), once
         if (u < nw * MAXF) {
             const int w = u / MAXF, f = u - w * MAXF;
@@ -167,6 +188,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         }
         __syncthreads();
         int item = sitem[0];
+        const int cellmask = __builtin_amdgcn_readfirstlane(scell);
         // (No register prefetch of the next item: it would cost 16 VGPRs across the whole walker loop, and with 128 per
         // wave that means scratch traffic inside the loop - measured 4x slower.  The other workgroup of the CU computes
         // while this one waits for its item at switch-in.)
@@ -188,9 +210,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #endif
             __syncthreads();                      // [D] the previous item's reduction has read `red` (and sitem)
             int t = fresh_tid();
-            if (__builtin_expect(item >= fa.nitB, 1)) {
+            if (__builtin_expect(item >= nF, 1)) {
                 // ================= catalogue chunk: piece A =================
-                const int c = item - fa.nitB;
+                const int c = item - nF;
                 // (wave-uniform by construction; said so, or they sit - and are spilled - in vector registers)
                 const int s0 = uni(sa.chunk_start[c]), n = uni(sa.chunk_len[c]), fld = uni(sa.chunk_field[c]);
                 // (kamax: the largest alpha_C key for which THIS WAVE's lanes fit one table piece each)
@@ -235,7 +257,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     const WalkerK p = pn;
                     pn = fetch(min(w + 1, nw - 1), fld);
                     double acc = 0.0;
-                    if (p.mode < MODE_SKIP && p.mode != MODE_SLOW && kc.tables && kfirst >= p.klo && klast <= p.khi && p.kac <= kamax) {
+                    if ((cellmask >> w) & 1) {
+                        // summed over the cells (its partials for source chunks are never read)
+                    } else if (p.mode < MODE_SKIP && p.mode != MODE_SLOW && kc.tables && kfirst >= p.klo && klast <= p.khi && p.kac <= kamax) {
                         TabCoef C;
                         if (kc.specialise && kfirst >= p.kne) {
                             asm volatile("; LF_BEGIN table_noexp items=%0" ::"n"(ST));
@@ -330,6 +354,46 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 __syncthreads();                  // [C]
                 t = fresh_tid();
                 reduce_store512(red, 0, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
+                item = sitem[0];
+            } else if (item >= fa.nitB) {
+                // ================= cell chunk: piece A of the walkers on cells =================
+                const int cc = item - fa.nitB;
+                const int c0 = uni(fa.cc_start[cc]), ncl = uni(fa.cc_len[cc]), fld = uni(fa.cc_field[cc]);
+                double cd[8];
+                if (t == 0) take_ticket();        // in front of the loads: back when they are
+                {
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.cells + (size_t)(c0 + min(t, ncl - 1)) * 8);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double2 a = src[k];
+                        cd[2 * k] = a.x;
+                        cd[2 * k + 1] = a.y;
+                    }
+                }
+                if (t >= ncl) {
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) cd[k] = 0.0;      // (no sources: every power sum 0)
+                }
+                if (t == 0) {
+                    asm volatile("" ::"v"(cd[7]));                  // (the loads - and the claim issued before them - have arrived)
+                    sitem[0] = redeem();
+                }
+#pragma unroll 1
+                for (int w = 0; w < nw; ++w) {
+                    double acc = 0.0;
+                    if ((cellmask >> w) & 1) {
+                        const WalkerK p = fetch(w, fld);
+                        asm volatile("; LF_BEGIN cell items=1");
+                        acc = cell_sum(cd, p, &tt);
+                        asm volatile("; LF_END cell");
+                        if (CENSUS && kc.forms && (t & 63) == 0)
+                            atomicAdd(kc.forms + FORM_CELL, (unsigned long long)min(max(ncl - (t & ~63), 0), 64));
+                    }
+                    red[w * PB + t] = acc;
+                }
+                __syncthreads();                  // [C]
+                t = fresh_tid();
+                reduce_store512(red, 0, nw, fa.partC, (size_t)fa.nchC, w0, cc, t);
                 item = sitem[0];
             } else {
                 // ================= node chunk: piece B =================

@@ -39,7 +39,16 @@ constexpr int WM = 8;        // ints per (walker, field) in wmode: {mode, klo, k
 // lumfuncmcmc.py:408): neither its terms nor its grid nodes are evaluated.  SKIPSRC: piece A is already known to be
 // -inf (NEGINF); the grid integral is still computed (lf_lnprob_pieces reports it).
 enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2, MODE_SKIP = 3, MODE_SKIPSRC = 4 };
-enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4 };   // SLOW: some field of the walker takes the careful path
+enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4,      // SLOW: some field of the walker takes the careful path
+       STAT_CELLS = 8 };   // FREE: piece A of this walker is summed over the catalogue's CELLS (lf_free.h), not its sources
+// Cells (FREE, real catalogue): a cell is a run of flux-neighbouring sources of one field no wider than 2 rho, stored as
+// {x_c, S_0 .. S_6}: its midpoint and the power sums S_j = sum_k (x_k - x_c)^j.  On a table piece the term is the
+// product of two degree-7 polynomials, g(t_c + sa d) h(u_c + d) = sum_j c_j d^j, so the cell's sum over its sources
+// is sum_j c_j S_j - whatever the number of sources.  Orders above CELL_M are dropped: with alpha_C rho <= CELL_RHO_G
+// and rho <= CELL_RHO_H their share of any term is below 3e-17 for every piece of both tables
+// (tests/test_tables_cpu.py recomputes that bound from the tables' coefficients).
+constexpr int CELL_M = 6;
+constexpr double CELL_RHO_G = 5.0e-3, CELL_RHO_H = 1.0e-3;
 
 // walker record, FREE / FIXCOMP: walker scalars ...
 enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4 };
@@ -52,7 +61,7 @@ __host__ __device__ constexpr int RF(int f, int slot) { return 8 + 8 * f + slot;
 enum { M_MODE = 0, M_KLO = 1, M_KHI = 2, M_KNE = 3, M_KAC = 4 };
 // slots of the census KConst::forms (lf_form_counts)
 enum { FORM_GENERAL = 0, FORM_GENERAL_NOEXP = 1, FORM_TABLE = 2, FORM_TABLE_NOEXP = 3, FORM_CAREFUL = 4, FORM_SKIPPED = 5,
-       FORM_NODE_GENERAL = 6, FORM_NODE_BRIGHT = 7, FORM_COUNT = 8 };
+       FORM_NODE_GENERAL = 6, FORM_NODE_BRIGHT = 7, FORM_CELL = 8, FORM_COUNT = 9 };
 constexpr double KEY_SCALE = 1048576.0;     // keys of log-flux: (x - x0) * 2^20, 1e-6 dex
 constexpr double KEY_ASCALE = 65536.0;      // keys of alpha_C
 constexpr int KEY_MAX = 2147483000;
@@ -62,6 +71,8 @@ enum { Z_AL = 0, Z_BL = 1, Z_CL = 2, Z_AP = 3, Z_BP = 4, Z_CP = 5, Z_C1 = 6 };
 struct KConst {
     int variant, fix_sch_al, nf, S, ndim;
     int specialise;           // 1: chunk-level term specialisation (term_free_noexp); 0 for A/B runs
+    int cells;                // FREE: 1 = the catalogue's cells exist and lf_prepare may flag walkers STAT_CELLS
+    int kf_first[MAXF], kf_last[MAXF];   // FREE: keys (floor / ceil) of each field's faintest / brightest source
     int grid_part, grid_parts; // source-sharded ranks split piece B too: this context integrates the node chunks c with
                               // c % grid_parts == grid_part (the others contribute 0); 0 / 1 = the whole grid
     double lnom0_src[MAXF];   // ln(trunc(Omega_0[f]) / sqarcsec)   (int-truncated, lumfuncmcmc.py:285)
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     const double SAFE = -700.0;
     bool ok = true;
     int neginf = 0, m = MODE_FAST;
+    int cell_ok = 1;       // FREE: this lane's field may be summed over its cells (see below)
     double base = 0.0;     // this lane's share of the walker-only part of piece A (closed form)
     if (kc.variant == LF_ZEVOL) {
         const double L1 = th[0], L2 = th[1], L3 = th[2], p1 = th[3], p2 = th[4], p3 = th[5];
@@ -354,24 +366,27 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
                 lF = log10(1.0e-17 * Flim);
                 V = 1.0 / (Flim * exp10(b));
                 const double cA = -alphaC * lF, cY = -(lF + b);
+                // Where the table-driven form of the term applies, as integer keys of log-flux x (conservatively
+                // rounded): num = alpha_C x + cA inside the g table, y = x + cY inside the h table, both with
+                // room for the margins; and from where on h = 1 (f / f_tau > 37.5: decay factor exactly 1.0).
+                int klo = KEY_MAX, khi = -1, kne = KEY_MAX, kac = KEY_MAX;
+                if (nqueue > 0 && alphaC > 0.0 && alphaC < 1.0e4) {      // (only lf_free reads the keys)
+                    const double xlo = fmax((G_NUM_LO + 2.0 * G_MARGIN - cA) / alphaC, H_LO + 2.0 * H_MARGIN - cY);
+                    const double xhi = (G_NUM_HI - 2.0 * G_MARGIN - cA) / alphaC;
+                    const double xne = 1.5740312677277188 - cY;            // log10(37.5)
+                    klo = key_ceil((xlo - kc.key_x0) * KEY_SCALE);
+                    khi = key_floor((xhi - kc.key_x0) * KEY_SCALE);
+                    kne = key_ceil((xne - kc.key_x0) * KEY_SCALE);
+                    kac = key_ceil(alphaC * KEY_ASCALE);
+                }
+                // the field's cells can stand for its sources when all of them lie inside the tables for this walker
+                // (their width was chosen for the prior box's largest alpha_C: lfmcmc.hip, build_cells)
+                cell_ok = kc.nsrc[f] == 0 || (klo <= kc.kf_first[f] && kc.kf_last[f] <= khi);
                 if (live) {
                     r[RF(f, F_LF)] = lF;
                     r[RF(f, F_V)] = V;
                     r[RF(f, F_CA)] = cA;
                     r[RF(f, F_CY)] = cY;
-                    // Where the table-driven form of the term applies, as integer keys of log-flux x (conservatively
-                    // rounded): num = alpha_C x + cA inside the g table, y = x + cY inside the h table, both with
-                    // room for the margins; and from where on h = 1 (f / f_tau > 37.5: decay factor exactly 1.0).
-                    int klo = KEY_MAX, khi = -1, kne = KEY_MAX, kac = KEY_MAX;
-                    if (nqueue > 0 && alphaC > 0.0 && alphaC < 1.0e4) {      // (only lf_free reads the keys)
-                        const double xlo = fmax((G_NUM_LO + 2.0 * G_MARGIN - cA) / alphaC, H_LO + 2.0 * H_MARGIN - cY);
-                        const double xhi = (G_NUM_HI - 2.0 * G_MARGIN - cA) / alphaC;
-                        const double xne = 1.5740312677277188 - cY;            // log10(37.5)
-                        klo = key_ceil((xlo - kc.key_x0) * KEY_SCALE);
-                        khi = key_floor((xhi - kc.key_x0) * KEY_SCALE);
-                        kne = key_ceil((xne - kc.key_x0) * KEY_SCALE);
-                        kac = key_ceil(alphaC * KEY_ASCALE);
-                    }
                     int* km = wmode + ((size_t)w * MAXF + f) * WM;
                     km[M_KLO] = klo;
                     km[M_KHI] = khi;
@@ -410,10 +425,13 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     if (bad) m = MODE_SKIP;
     else if (neginf) m = MODE_SKIPSRC;
     const int slow = group8_or(has_f && m == MODE_SLOW ? 1 : 0);
+    // cells: only walkers whose every field is FAST and inside the tables (all the others are rare, and summed per source)
+    const int nocell = group8_or(has_f && !(cell_ok && (m == MODE_FAST || kc.nsrc[f] == 0)) ? 1 : 0);
+    const int cells = kc.cells && kc.variant == LF_FREE && nqueue > 0 && !bad && !neginf && !nocell;
     if (live && has_f) wmode[((size_t)w * MAXF + f) * WM + M_MODE] = m;
     if (live && f == 0) {
         wbase[w] = base;
-        wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0);
+        wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0) | (cells ? STAT_CELLS : 0);
         if (slow && slow_list) slow_list[1 + atomicAdd(slow_list, 1)] = w;
     }
 }
@@ -890,6 +908,41 @@ __device__ __forceinline__ double table_terms(const TabCoef& C, const double (&x
     return fma(-(double)npad, last, sum);
 }
 
+// One cell for one walker: sum over the cell's sources of g(num) h(y) = sum_j c_j S_j (see CELL_M above).  cd = {x_c,
+// S_0 .. S_6}.  Per (walker, cell): the piece lookup at x_c, the Taylor shifts of both piece polynomials to the cell's
+// midpoint (28 FMAs each for orders 0 .. 6 of a degree-7 polynomial), the powers of the slope, the product series and
+// the dot product with the power sums: ~125 fp64 instructions whatever the number of sources in the cell.
+__device__ __forceinline__ double cell_sum(const double (&cd)[8], const WalkerK& p, const TermTables* __restrict__ tt) {
+    TabCoef C;
+    const double xs[1] = {cd[0]};
+    table_lookup<1>(C, xs, p, false, tt);          // (bright cells land on the h table's last piece, the constant 1)
+    const double tc = fma(C.sa, cd[0], C.sc), uc = cd[0] + C.dy;
+#pragma unroll
+    for (int j = 0; j <= CELL_M; ++j) {
+#pragma unroll
+        for (int i = 6; i >= j; --i) {
+            C.cg[i] = fma(tc, C.cg[i + 1], C.cg[i]);
+            C.ch[i] = fma(uc, C.ch[i + 1], C.ch[i]);
+        }
+    }
+    // g in powers of d = x - x_c: (sa d)^j
+    double pw = C.sa;
+#pragma unroll
+    for (int j = 1; j <= CELL_M; ++j) {
+        C.cg[j] *= pw;
+        if (j < CELL_M) pw *= C.sa;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = CELL_M; j >= 0; --j) {             // (small terms first)
+        double cj = C.cg[0] * C.ch[j];
+#pragma unroll
+        for (int i = 1; i <= j; ++i) cj = fma(C.cg[i], C.ch[j - i], cj);
+        acc = fma(cj, cd[1 + j], acc);
+    }
+    return acc;
+}
+
 // ----------------------------------------------------------------------------------------------
 // piece B: expected-count integral on the S x S grid.  grid = (node chunks of 256, walker tiles)
 // trapz(trapz(I, logL, axis=0), zarr) = sum_jk W_jk I_jk with W from the actual grid spacings.
@@ -1253,7 +1306,7 @@ __global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __r
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,
                                                   const double* __restrict__ partB, int nchB, int strideB,
-                                                  const double* __restrict__ partR, int nchR,
+                                                  const double* __restrict__ partR, int nchR, int alt_flag,
                                                   const int* __restrict__ wstat,
                                                   const double* __restrict__ wbase, int B, AcceptArgs ap,
                                                   double* __restrict__ out, double* __restrict__ outA,
@@ -1263,8 +1316,9 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
     if (slow_list && w == 0 && threadIdx.x == 0) slow_list[0] = 0;     // lf_main has consumed the list
     const int lane = threadIdx.x;
     double a = 0.0, b = 0.0;
-    // compressed catalogue: a walker flagged SLOW was summed over the real catalogue by the rescue workgroups
-    const bool resc = partR != nullptr && (wstat[w] & STAT_SLOW);
+    // piece A of a walker with the alt_flag bit lies in partR: the compressed catalogue's SLOW walkers, summed over the
+    // real catalogue by the rescue workgroups (alt_flag = STAT_SLOW); lf_free's walkers summed over cells (STAT_CELLS)
+    const bool resc = partR != nullptr && (wstat[w] & alt_flag);
     const double* pa = resc ? partR + (size_t)w * nchR : partA + (size_t)w * strideA;
     const double* pb = partB + (size_t)w * strideB;
     if (resc) nchA = nchR;

@@ -87,7 +87,11 @@ __device__ __forceinline__ double flog_half(double w, const MathTables* __restri
     const double2 t = mt->logt[j];
     const double r = fma(m, t.x, -1.0);
     double p = fma(r, 0.2, -0.25);                                   // |r| < 2^-9: r^6/6 < 1e-17
-    p = fma(p, r, 1.0 / 3.0);
+    // (a scalar-register constant made HERE: left to the compiler it is hoisted out of lf_free's item loop into a vector
+    // register pair and spilled - the one scratch slot of that kernel)
+    double third = 1.0 / 3.0;
+    asm volatile("" : "+s"(third));
+    p = fma(p, r, third);
     p = fma(p, r, -0.5);
     const double r2 = r * r;
     const double hi_part = fma((double)e, LF_LN2, t.y);

@@ -60,6 +60,13 @@ struct lf_ctx {
     unsigned long long* d_forms = nullptr;   // census of the term forms (option "count_forms"), FORM_COUNT slots
     int last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lf_last_launch
     int* d_queue = nullptr;              // FREE: item counters of the persistent workgroups, [tiles][lf::QSTRIDE]
+    // FREE: the catalogue's cells (lf_kernels.h: CELL_M) - {x_c, S_0 .. S_6} per cell, chunks of <= 512 cells of one field
+    double* d_cells = nullptr;           // [ncell][8]
+    int* d_cc_start = nullptr;           // [ncchunk] first cell of the chunk
+    int* d_cc_len = nullptr;             // [ncchunk] cells in the chunk (<= 512)
+    int* d_cc_field = nullptr;           // [ncchunk]
+    int ncell = 0, ncchunk = 0;
+    int64_t opt_cells = 1;               // 0: sum every walker over the sources (A/B runs)
     int cap_queue = 0;
     int slots_free[3] = {0, 0, 0};       // workgroups of lf_free<2 / 4 / 8> the chip holds at once (0 = not asked yet)
     int num_cu = 0;
@@ -126,6 +133,65 @@ template <typename T>
 int upload(lf_ctx* c, T** dst, const T* src, size_t n) {
     LF_HIP(c, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
     if (n) LF_HIP(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return LF_OK;
+}
+
+// The cells of a FREE catalogue (lf_kernels.h: CELL_M): runs of flux-neighbouring sources of one field no wider than
+// 2 rho, rho = min(CELL_RHO_H, CELL_RHO_G / alpha_hi) with alpha_hi the prior box's largest alpha_C (walkers outside the
+// box are -inf before any sum is looked at).  x = the flux-sorted logf.  Walker-independent: built once.  A field with a
+// non-finite flux, or a prior box so wide in alpha_C that cells would hold fewer than four sources on average, gets
+// none (kc.cells = 0: every walker is summed over the sources, as before).
+int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf) {
+    using namespace lf;
+    const double ahi = kc.lims[LF_LIM_ALPHA][1];
+    if (!(ahi > 0.0) || !std::isfinite(ahi)) return LF_OK;
+    const double rho = std::fmin(CELL_RHO_H, CELL_RHO_G / ahi);
+    std::vector<double> cd;
+    std::vector<int> cst, cln, cfl;
+    for (int f = 0; f < nf; ++f) {
+        const int64_t lo = c->field_ind[f], hi = c->field_ind[f + 1];
+        if (hi <= lo) continue;
+        for (int64_t i = lo; i < hi; ++i)
+            if (!std::isfinite(x[(size_t)i])) return LF_OK;
+        const double k0 = std::floor((x[(size_t)lo] - kc.key_x0) * KEY_SCALE), k1 = std::ceil((x[(size_t)hi - 1] - kc.key_x0) * KEY_SCALE);
+        if (!(k0 >= 0.0 && k1 < (double)KEY_MAX)) return LF_OK;
+        kc.kf_first[f] = (int)k0;
+        kc.kf_last[f] = (int)k1;
+        const size_t first_cell = cd.size() / 8;
+        for (int64_t i = lo; i < hi;) {
+            int64_t j = i + 1;
+            while (j < hi && x[(size_t)j] - x[(size_t)i] <= 2.0 * rho) ++j;
+            const double xc = 0.5 * (x[(size_t)i] + x[(size_t)j - 1]);
+            long double S[CELL_M + 1] = {0};
+            for (int64_t k = i; k < j; ++k) {
+                const long double dlt = (long double)x[(size_t)k] - (long double)xc;
+                long double pw = 1.0L;
+                for (int m = 0; m <= CELL_M; ++m) {
+                    S[m] += pw;
+                    pw *= dlt;
+                }
+            }
+            cd.push_back(xc);
+            for (int m = 0; m <= CELL_M; ++m) cd.push_back((double)S[m]);
+            i = j;
+        }
+        const size_t ncf = cd.size() / 8 - first_cell;
+        for (size_t s0 = 0; s0 < ncf; s0 += (size_t)PB) {
+            cst.push_back((int)(first_cell + s0));
+            cln.push_back((int)std::min<size_t>((size_t)PB, ncf - s0));
+            cfl.push_back(f);
+        }
+    }
+    const size_t ncell = cd.size() / 8;
+    if (ncell == 0 || (size_t)c->N < 4 * ncell) return LF_OK;         // (too few sources per cell to pay)
+    int rc;
+    if ((rc = upload(c, &c->d_cells, cd.data(), cd.size())) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_cc_start, cst.data(), cst.size())) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_cc_len, cln.data(), cln.size())) != LF_OK) return rc;
+    if ((rc = upload(c, &c->d_cc_field, cfl.data(), cfl.size())) != LF_OK) return rc;
+    c->ncell = (int)ncell;
+    c->ncchunk = (int)cst.size();
+    kc.cells = c->opt_cells ? 1 : 0;
     return LF_OK;
 }
 
@@ -424,7 +490,7 @@ void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa
     }
     // groups of 8 workgroups (one per XCD under round-robin placement) per tile; no more than the chip holds at once,
     // no more than there are items
-    const int64_t per_tile = ((int64_t)fa.nchA + fa.nitB + 7) / 8;
+    const int64_t per_tile = ((int64_t)fa.nchA + fa.nitB + fa.nchC + 7) / 8;
     const int64_t g8 = std::max<int64_t>(1, std::min<int64_t>(c->slots_free[slot] / 8, (int64_t)ntiles * std::max<int64_t>(per_tile, 1)));
     fa.tile_stride = (int)g8;
     const dim3 grid((unsigned)(8 * g8));
@@ -446,7 +512,8 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     const int nchA = ct->n;
     const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + PB - 1) / PB;
     const int nsplit = fs.nsplit;
-    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1));
+    const int nchC = c->kc.cells ? c->ncchunk : 0;
+    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * std::max(nchC, 1));
     if (rc != LF_OK) return rc;
     if (ntiles * QSTRIDE > c->cap_queue) {
         LF_HIP(c, hipDeviceSynchronize());
@@ -466,7 +533,8 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     }
     const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
     const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
-    FreeArgs fa{B, ntiles, nchA, nchB, nsplit, nchB * nsplit, PTW / nsplit, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB};
+    FreeArgs fa{B, ntiles, nchA, nchB, nsplit, nchB * nsplit, PTW / nsplit, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
+                c->d_cells, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat};
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
@@ -478,7 +546,8 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           (const double*)nullptr, 0, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB, (int*)nullptr);
+                           nchC > 0 ? (const double*)c->d_partR : (const double*)nullptr, nchC, (int)STAT_CELLS, c->d_wstat, c->d_wbase, B, ap,
+                           d_out, d_outA, d_outB, (int*)nullptr);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;
@@ -500,9 +569,14 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         // 256 rows: 29 / 79, 50 / 56, 91 / 72, 327 / 205; N = 1e5 with 512 rows: 127 / 120): the persistent kernel wins
         // once every one of its ~512 workgroups gets about four items or more; below that its coarse items cost more
         // than its tables save.  opt_persistent = 2 or an explicit free_st force it (tests, tuning runs).
+        // With the catalogue's cells (the normal case) piece A costs next to nothing and the kernel takes 22-34 us up to
+        // 128 rows whatever N is (the grid integral): it wins from N x rows ~ 1e7 (lf_main / lf_free, 128 rows: N = 5e4
+        // 32 / 34, 1e5 40 / 33, 2.5e5 60 / 33; N = 1e6 with 16 / 32 / 64 rows: 30 / 24, 50 / 25, 94 / 30; N = 1e5 with
+        // 32 / 512 rows: 16 / 25, 126 / 88).
         const int64_t ntiles = (B + PTW - 1) / PTW;
         const int64_t items = free_shape(c).items_per_tile * ntiles;
-        if (items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1) || c->opt_persistent == 2 || c->opt_free_st)
+        const bool wins = c->kc.cells ? c->N * (int64_t)B >= 10000000 : items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1);
+        if (wins || c->opt_persistent == 2 || c->opt_free_st)
             return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     }
     // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
@@ -613,7 +687,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           cmp ? c->d_partR : nullptr, nchD, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB,
+                           cmp ? c->d_partR : nullptr, nchD, (int)STAT_SLOW, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB,
                            cmp ? c->d_slow : nullptr);
     }
     LF_HIP(c, hipGetLastError());
@@ -822,6 +896,10 @@ void free_ctx(lf_ctx* c) {
     }
     free_cmp(c->cmp);
     if (c->d_partR) hipFree(c->d_partR);
+    if (c->d_cells) hipFree(c->d_cells);
+    if (c->d_cc_start) hipFree(c->d_cc_start);
+    if (c->d_cc_len) hipFree(c->d_cc_len);
+    if (c->d_cc_field) hipFree(c->d_cc_field);
     {
         auto& g = c->gridc;
         double* gb[] = {g.d_U, g.d_A4, g.d_omega, g.d_L, g.d_PGL};
@@ -985,6 +1063,12 @@ int build(lf_ctx* c, const lf_desc* d) {
         c->h_x = a1;
     }
     int rc;
+    kc.cells = 0;
+    for (int f = 0; f < MAXF; ++f) {
+        kc.kf_first[f] = 0;
+        kc.kf_last[f] = lf::KEY_MAX;
+    }
+    if (d->variant == LF_FREE && (rc = build_cells(c, kc, a1, nf)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_lum, lumv.data(), (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a1, a1.data(), (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_P, P.data(), (size_t)N)) != LF_OK) return rc;
@@ -1309,7 +1393,7 @@ int lf_last_launch(const lf_ctx* c, int32_t info[8]) {
     return LF_OK;
 }
 
-int lf_form_counts(lf_ctx* c, int64_t counts[8]) {
+int lf_form_counts(lf_ctx* c, int64_t counts[9]) {
     if (!c || !counts) return LF_ERR_ARG;
     for (int i = 0; i < lf::FORM_COUNT; ++i) counts[i] = 0;
     if (!c->d_forms) return LF_OK;
@@ -1369,6 +1453,11 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             return LF_ERR_ARG;
         }
         c->opt_free_st = value;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "cells") == 0) {
+        c->opt_cells = value != 0;
+        c->kc.cells = c->opt_cells && c->ncell > 0;
         return LF_OK;
     }
     if (std::strcmp(key, "node_split") == 0) {

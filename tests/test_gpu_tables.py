@@ -24,6 +24,7 @@ def test_table_form_equals_general_form(n, wide):
     inp = make_inputs("free", n, seed=91)
     ctx = LFContext(inp)
     ctx.set_option("persistent", 2)                # lf_free whatever the size (auto: only when it pays)
+    ctx.set_option("cells", 0)                     # this test is about the per-source forms
     th = _rows(96, 92, wide)
     th[5, 0] = 40.2                                # underflow zone: -inf
     th[6, 1] = 6.0                                 # outside the prior
@@ -103,6 +104,7 @@ def test_table_form_against_the_oracle():
     inp = make_inputs("free", 300007, seed=93)
     ctx = LFContext(inp)
     ctx.set_option("persistent", 2)
+    ctx.set_option("cells", 0)
     th = _rows(6, 94)
     ctx.set_option("count_forms", 1)
     a, b = ctx.lnprob_pieces(th)
@@ -121,6 +123,7 @@ def test_census_adds_up():
     inp = make_inputs("free", 250000, seed=95)
     ctx = LFContext(inp)
     ctx.set_option("persistent", 2)
+    ctx.set_option("cells", 0)
     th = _rows(40, 96, wide=True)
     th[3, 8] = 9.0                                 # outside the prior: its terms are counted as skipped
     ctx.set_option("count_forms", 1)
@@ -131,3 +134,62 @@ def test_census_adds_up():
     assert src == 40 * 250000, fc
     assert fc["skipped"] == 250000
     assert fc["node_general"] + fc["node_bright"] == 39 * 101 * 101 * 5, fc
+
+
+# ---------------------------------------------------------------------------------------------- cells
+@pytest.mark.parametrize("n,nf,B", [(400003, 5, 96), (1000000, 5, 130), (60011, 3, 33), (33000, 8, 9)])
+def test_cells_equal_the_sum_over_sources(n, nf, B):
+    """lf_free summing walkers over the catalogue's cells (midpoint + power sums of a narrow flux interval, lf_kernels.h:
+    CELL_M) against the same kernel summing them over the sources ("cells" = 0) and against the oracle: walkers over the
+    whole prior box of the completeness parameters, -inf rows, a row outside the prior, ragged tiles."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", n, seed=51, nf=nf)
+    ctx = LFContext(inp, max_batch=max(B, 64))
+    ctx.set_option("persistent", 2)
+    th = synth.walkers("free", B, seed=52, nf=nf)
+    rng = np.random.default_rng(53)
+    k = B // 2
+    th[k:, 3:3 + nf] = rng.uniform(1.0, 6.0, (B - k, nf))
+    th[k:, 3 + nf] = rng.uniform(1.0, 7.0, B - k)
+    th[1, 0] = 40.2                                # underflow zone: -inf
+    th[2, 1] = 6.0                                 # outside the prior
+    ctx.set_option("count_forms", 1)
+    a1, b1 = ctx.lnprob_pieces(th)
+    lp1 = ctx.lnprob_batch(th)
+    fc = ctx.form_counts()
+    ctx.set_option("count_forms", 0)
+    ctx.set_option("cells", 0)
+    a0, b0 = ctx.lnprob_pieces(th)
+    lp0 = ctx.lnprob_batch(th)
+    ctx.close()
+    if n >= 60000:
+        assert fc["cell"] > 0, fc                                           # (the cells did run)
+        assert fc["cell"] < 0.2 * (B - 2) * n * 2, fc                       # ... and are far fewer than the sources
+    else:
+        assert fc["cell"] == 0, fc                                          # (4125 sources per field: under four per cell, no cells)
+    assert np.array_equal(np.isinf(lp1), np.isinf(lp0)) and not np.isnan(lp1).any()
+    assert np.isinf(lp1[1]) and np.isinf(lp1[2])
+    fin = np.isfinite(lp0)
+    np.testing.assert_allclose(a1[fin], a0[fin], rtol=2e-14)                # the orders dropped: < 3e-17 per term
+    np.testing.assert_array_equal(b1[fin], b0[fin])
+    ref = O.lnprob_batch(inp, th[:8])
+    compare_rows(lp1[:8], ref, inp, th[:8], 1e-12)
+
+
+def test_cells_are_not_used_when_they_cannot_be():
+    """A non-finite flux in the catalogue, or a prior box so wide in alpha_C that a cell would be a source: no cells, every
+    walker over the sources, same results as ever."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", 120000, seed=55)
+    inp["lims"] = {k: list(v) for k, v in inp["lims"].items()}
+    inp["lims"]["alpha"] = [1.0, 4000.0]
+    th = _rows(16, 56)
+    ref = O.lnprob_batch(inp, th)
+    ctx = LFContext(inp)
+    ctx.set_option("persistent", 2)
+    ctx.set_option("count_forms", 1)
+    got = ctx.lnprob_batch(th)
+    fc = ctx.form_counts()
+    ctx.close()
+    assert fc["cell"] == 0 and fc["table"] + fc["table_noexp"] > 0, fc
+    compare_rows(got, ref, inp, th, 1e-12)

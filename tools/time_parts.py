@@ -56,7 +56,7 @@ def main():
             spec, 1e3 * kt["main"]["ms"] / max(kt["main"]["launches"], 1), 1e3 * kt["prepare"]["ms"] / max(kt["prepare"]["launches"], 1),
             1e3 * kt["finalize"]["ms"] / max(kt["finalize"]["launches"], 1), ctx.last_launch()), flush=True)
         for k, v in opts:
-            ctx.set_option(k, {"tables": 1, "specialise": 1, "persistent": 1}.get(k, 0))      # back to the defaults
+            ctx.set_option(k, {"tables": 1, "specialise": 1, "persistent": 1, "cells": 1}.get(k, 0))      # back to the defaults
 
 
 if __name__ == "__main__":
