@@ -56,7 +56,7 @@ struct FreeArgs {
     // cells (lf_kernels.h: CELL_M): walkers flagged STAT_CELLS by lf_prepare are summed over them instead of the sources
     const double* cells;      // [ncell][8] {x_c, S_0 .. S_6}
     const int* cc_start;      // [nchC] first cell of a cell chunk
-    const int* cc_len;        // [nchC] its cells (<= 512: one per lane)
+    const int* cc_len;        // [nchC] its cells (<= 64: one per lane of a wave; the waves take one walker each)
     const int* cc_field;      // [nchC]
     int nchC;                 // cell chunks: items nitB .. nitB + nchC - 1 of the tile's front queue (0: no cells)
     double* partC;            // [B][nchC]
@@ -113,13 +113,19 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         int* __restrict__ q = fa.queues + tile * QSTRIDE;
         // next item of this tile: a node chunk while there are any (item = chunk), then a catalogue chunk of our XCD's
         // queue, or of the next queue that still has some (item = nitB + chunk); -1 = the tile is done
-        const int nF = fa.nitB + fa.nchC;          // front queue: grid items, then cell chunks
+        const int nF = fa.nitB;                    // front items: the grid items (the cell chunks are dealt the same way, per wave)
+        // The front items all cost about the same (and with every walker on cells they are all there is): they are dealt
+        // STATICALLY, item i to the workgroup of rank i mod fgroup among those serving the tile - no claims, whose round
+        // trips (microseconds each, every workgroup of a tile on one counter) were most of a launch of small items.
+        // Only the source chunks - unequal, and only needed by walkers that cannot use the cells - are claimed from queues.
+        int fgroup = 8, frank = (int)blockIdx.x & 7;
+        if (fa.ntiles <= fa.tile_stride) {
+            const int k = (int)blockIdx.x >> 3;   // (here tile = k mod ntiles, and the groups k, k + ntiles, ... share it)
+            fgroup = 8 * ((fa.tile_stride - tile + fa.ntiles - 1) / fa.ntiles);
+            frank += 8 * ((k - tile) / fa.ntiles);
+        }
         bool no_src = false;                       // (thread 0's view) every walker of the tile is summed over the cells
         auto grab = [&]() -> int {
-            if (nF > 0) {
-                const int i = atomicAdd(q, 1);
-                if (i < nF) return i;
-            }
             if (no_src) return -1;
             for (int d = 0; d < 8; ++d) {
                 const int qq = (myq + d) & 7;
@@ -136,17 +142,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         // arrived: one round trip for both.  The result goes to LDS at once: kept in a register across the walker loop
         // it is spilled, and the spill waits for the atomic on the spot.  (build.py keeps the compiler's atomic
         // optimizer from reading the one-lane atomic's result where it is issued.)
-        bool grid_dry = nF <= 0;                           // (thread 0's view)
         int ticket = 0;
         auto take_ticket = [&]() {
-            if (!(grid_dry && no_src)) ticket = atomicAdd(grid_dry ? q + 1 + myq : q, 1);
+            if (!no_src) ticket = atomicAdd(q + 1 + myq, 1);
         };
         auto redeem = [&]() -> int {
-            if (!grid_dry) {
-                if (ticket < nF) return ticket;
-                grid_dry = true;
-                return grab();
-            }
             if (no_src) return -1;
             const int lo = (int)(((long long)myq * fa.nchA) >> 3), hi = (int)(((long long)(myq + 1) * fa.nchA) >> 3);
             if (ticket < hi - lo) return nF + lo + ticket;
@@ -154,14 +154,16 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         };
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
         const int u = fresh_tid();
-        if (u == 0) {
-            // which walkers of the tile lf_prepare put on the cells; when all of them are, the sources are not touched
-            int m = 0;
-            if (fa.nchC > 0)
-                for (int w = 0; w < nw; ++w) m |= (fa.wstat[w0 + w] & STAT_CELLS) ? 1 << w : 0;
-            scell = m;
-            no_src = fa.nchC > 0 && m == (1 << nw) - 1;
-            sitem[0] = grab();
+        if (u < 64) {
+            // which walkers of the tile lf_prepare put on the cells (one load per lane); when all of them are, the sources
+            // are not touched
+            const bool on = fa.nchC > 0 && u < nw && (fa.wstat[w0 + min(u, nw - 1)] & STAT_CELLS);
+            const int m = (int)__ballot(on);
+            if (u == 0) {
+                scell = m;
+                no_src = fa.nchC > 0 && m == (1 << nw) - 1;
+                if (frank >= nF) sitem[0] = grab();
+            }
         }
         // the tile's walker constants, all fields (64 B per (walker, field)), once
         if (u < nw * MAXF) {
@@ -187,7 +189,6 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             if (w < nw) wsc[t] = wrec[(size_t)(w0 + w) * REC + j];
         }
         __syncthreads();
-        int item = sitem[0];
         const int cellmask = __builtin_amdgcn_readfirstlane(scell);
         // (No register prefetch of the next item: it would cost 16 VGPRs across the whole walker loop, and with 128 per
         // wave that means scratch traffic inside the loop - measured 4x slower.  The other workgroup of the CU computes
@@ -201,6 +202,61 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             return WalkerK{a.x, b.x, b.y, c.y, km[M_MODE], km[M_KLO], km[M_KHI], km[M_KNE], km[M_KAC]};
         };
 
+        // ---- cells: piece A of the walkers on cells.  64 cells per chunk, one WALKER PER WAVE (lane = cell): a wave sums its
+        // walker over this workgroup's share of the tile's cell chunks on its own - no LDS, no barrier, the next chunk's
+        // cells in flight while the current one is summed - and writes one partial per chunk from the DPP network.
+        {
+            const int v = wave_base >> 6;
+            if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && frank < fa.nchC) {       // (wave-uniform)
+                auto load_cells = [&](double (&d)[8], int cc) {
+                    const int lane = fresh_tid() & 63;      // (made here: carried through the loop it is spilled in one instantiation)
+                    const int c0 = uni(fa.cc_start[cc]), ncl = uni(fa.cc_len[cc]);
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.cells + (size_t)(c0 + min(lane, ncl - 1)) * 8);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double2 a = src[k];
+                        d[2 * k] = lane < ncl || k == 0 ? a.x : 0.0;     // (x_c always; a lane past the end: every power sum 0)
+                        d[2 * k + 1] = lane < ncl ? a.y : 0.0;
+                    }
+                };
+                double nx[8];
+                load_cells(nx, frank);
+#pragma unroll 1
+                for (int cc = frank; cc < fa.nchC; cc += fgroup) {
+                    double cd[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cd[k] = nx[k];
+                    if (cc + fgroup < fa.nchC) load_cells(nx, cc + fgroup);
+                    const WalkerK p = fetch(v, uni(fa.cc_field[cc]));
+                    asm volatile("; LF_BEGIN cell items=1");
+                    double acc = cell_sum(cd, p, &tt);
+                    asm volatile("; LF_END cell");
+                    const int ln = fresh_tid() & 63;
+                    if (CENSUS && kc.forms && ln == 0) atomicAdd(kc.forms + FORM_CELL, (unsigned long long)uni(fa.cc_len[cc]));
+                    acc = wave_sum_dpp(acc);      // lane 63: the wave's total
+                    if (ln == 63) fa.partC[(size_t)(w0 + v) * fa.nchC + cc] = acc;
+                }
+            }
+        }
+        int fnext = frank;                        // this workgroup's next front item
+        int item;
+        if (fnext < nF) {
+            item = fnext;
+            fnext += fgroup;
+        } else {
+            item = sitem[0];
+        }
+        // after a front item: the next one of this workgroup's share, or - once - the first claim from the source queues
+        auto after_front = [&](int t) -> int {
+            if (fnext < nF) {
+                const int it = fnext;
+                fnext += fgroup;
+                return it;
+            }
+            if (t == 0) sitem[0] = grab();
+            __syncthreads();
+            return sitem[0];
+        };
 #pragma unroll 1
         while (item >= 0) {
 #ifdef LF_STAMPS
@@ -355,46 +411,6 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 t = fresh_tid();
                 reduce_store512(red, 0, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
                 item = sitem[0];
-            } else if (item >= fa.nitB) {
-                // ================= cell chunk: piece A of the walkers on cells =================
-                const int cc = item - fa.nitB;
-                const int c0 = uni(fa.cc_start[cc]), ncl = uni(fa.cc_len[cc]), fld = uni(fa.cc_field[cc]);
-                double cd[8];
-                if (t == 0) take_ticket();        // in front of the loads: back when they are
-                {
-                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.cells + (size_t)(c0 + min(t, ncl - 1)) * 8);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const double2 a = src[k];
-                        cd[2 * k] = a.x;
-                        cd[2 * k + 1] = a.y;
-                    }
-                }
-                if (t >= ncl) {
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) cd[k] = 0.0;      // (no sources: every power sum 0)
-                }
-                if (t == 0) {
-                    asm volatile("" ::"v"(cd[7]));                  // (the loads - and the claim issued before them - have arrived)
-                    sitem[0] = redeem();
-                }
-#pragma unroll 1
-                for (int w = 0; w < nw; ++w) {
-                    double acc = 0.0;
-                    if ((cellmask >> w) & 1) {
-                        const WalkerK p = fetch(w, fld);
-                        asm volatile("; LF_BEGIN cell items=1");
-                        acc = cell_sum(cd, p, &tt);
-                        asm volatile("; LF_END cell");
-                        if (CENSUS && kc.forms && (t & 63) == 0)
-                            atomicAdd(kc.forms + FORM_CELL, (unsigned long long)min(max(ncl - (t & ~63), 0), 64));
-                    }
-                    red[w * PB + t] = acc;
-                }
-                __syncthreads();                  // [C]
-                t = fresh_tid();
-                reduce_store512(red, 0, nw, fa.partC, (size_t)fa.nchC, w0, cc, t);
-                item = sitem[0];
             } else {
                 // ================= node chunk: piece B =================
                 int sub = 0, c = item;                                                             // walker sub-tile, chunk
@@ -405,11 +421,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int wlo = sub * fa.wpn, whi = min(wlo + fa.wpn, nw);                         // (empty for a ragged last tile)
                 const bool valid = c * PB + t < na.nnodes;
                 const int g = min(c * PB + t, na.nnodes - 1);
-                if (t == 0) take_ticket();        // in front of the loads: back when they are
                 const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0, a3 = na.a3[g], a4 = na.a4[g];
                 const double a4min = fmin(na.a4min[2 * c], na.a4min[min(2 * c + 1, (na.nnodes + BLOCK - 1) / BLOCK - 1)]);   // wave-uniform
-                asm volatile("" ::"v"(G), "v"(PG), "v"(W), "v"(a3), "v"(a4), "v"(a4min));      // (the loads have arrived)
-                if (t == 0) sitem[0] = redeem();
                 const int nodes_here = min(PB, na.nnodes - c * PB);
 #pragma unroll 1
                 for (int w = wlo; w < whi; ++w) {
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 __syncthreads();                  // [C]
                 t = fresh_tid();
                 reduce_store512(red, wlo, whi, fa.partB, (size_t)fa.nchB, w0, c, t);
-                item = sitem[0];
+                item = after_front(t);
             }
 #ifdef LF_STAMPS
             ++nitems_done;

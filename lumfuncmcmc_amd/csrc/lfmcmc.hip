@@ -63,7 +63,7 @@ struct lf_ctx {
     // FREE: the catalogue's cells (lf_kernels.h: CELL_M) - {x_c, S_0 .. S_6} per cell, chunks of <= 512 cells of one field
     double* d_cells = nullptr;           // [ncell][8]
     int* d_cc_start = nullptr;           // [ncchunk] first cell of the chunk
-    int* d_cc_len = nullptr;             // [ncchunk] cells in the chunk (<= 512)
+    int* d_cc_len = nullptr;             // [ncchunk] cells in the chunk (<= 64)
     int* d_cc_field = nullptr;           // [ncchunk]
     int ncell = 0, ncchunk = 0;
     int64_t opt_cells = 1;               // 0: sum every walker over the sources (A/B runs)
@@ -176,9 +176,9 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf)
             i = j;
         }
         const size_t ncf = cd.size() / 8 - first_cell;
-        for (size_t s0 = 0; s0 < ncf; s0 += (size_t)PB) {
+        for (size_t s0 = 0; s0 < ncf; s0 += 64) {                       // a cell chunk = one wave's lanes (lf_free.h)
             cst.push_back((int)(first_cell + s0));
-            cln.push_back((int)std::min<size_t>((size_t)PB, ncf - s0));
+            cln.push_back((int)std::min<size_t>(64, ncf - s0));
             cfl.push_back(f);
         }
     }
