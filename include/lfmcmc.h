@@ -149,8 +149,7 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * hold the g / h tables in LDS, serve one tile of 8 walkers and pull catalogue and grid chunks from per-XCD queues -
  * whenever the catalogue and the grid give every workgroup about four items (e.g. N >= 1.8e5 at 128 rows, N = 1e6
  * from 64 rows); 0 = always lf_main; 2 = always lf_free (tests).  "free_st": sources per lane of lf_free, 0 (auto: 8
- * for N >= 3e5, else 4), 2, 4 or 8; "node_split": grid items per (node chunk, walker tile), 0 (auto: 2), 1, 2, 4 or 8
- * (tuning runs).  "cells": 1 (default) lets lf_free sum a walker whose every field lies inside the tables over the
+ * for N >= 3e5, else 4), 2, 4 or 8 (tuning runs).  "cells": 1 (default) lets lf_free sum a walker whose every field lies inside the tables over the
  * catalogue's CELLS instead of its sources: runs of flux-neighbouring sources no wider than 2 rho, kept as their
  * midpoint and power sums S_0 .. S_6; on a table piece the term is a polynomial in the flux offset, so a cell's sum is
  * a dot product of its Taylor coefficients with the power sums, exact up to the orders above 6, whose share is below

@@ -28,8 +28,13 @@ def is_stale():
 
 # -amdgpu-atomic-optimizer-strategy=None: lf_free's one-lane queue claims must stay plain returning atomics whose
 # result is waited for where it is USED (half an item later); the optimizer's wave-aggregated form reads it at once.
+# -disable-machine-licm: left on, the pass lifts the materialisation of every fp64 literal of every inlined routine (the
+# device library's exp and log of the careful path among them: 14 coefficients) to the top of the kernel, where they
+# hold vector registers for the kernel's whole life: lf_free sat at its 128-register cap and spilled, with it off it
+# needs 86 and nothing spills.  Measured on the MI355X: lf_free 31.6 -> 29.5 us (10^6 sources, 128 rows), 31.8 -> 28.9
+# (10^5), lf_main 24.0 -> 20.8 (10^3); only the z-evolving lf_main pays (82.3 -> 85.0 us).
 CXXFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-            "-Wno-unused-value", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+            "-Wno-unused-value", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-disable-machine-licm"]
 
 
 def build_library(force=False, verbose=True, extra_flags=()):

@@ -43,23 +43,21 @@ __device__ __forceinline__ void reduce_store512(const double* __restrict__ red, 
 
 struct FreeArgs {
     int B, ntiles;            // theta rows, tiles of PTW walkers
-    int nchA, nchB;           // catalogue chunks (512 ST sources), node chunks (512 nodes)
-    int nsplit;               // a node chunk is served in nsplit items of PTW / nsplit walkers each (1, 2 or 4): finer items
-                              // when the catalogue is small and the grid is half of the work
-    int nitB;                 // = nchB * nsplit: grid items per tile (item = sub-tile * nchB + chunk)
-    int wpn;                  // = PTW / nsplit: walkers per grid item
+    int nchA, nchB;           // catalogue chunks (512 ST sources), node chunks (64 nodes)
+    int nslot;                // slots per walker in partB / partC: one per workgroup serving the walker's tile (the largest
+                              // such number over the tiles; a tile with fewer workgroups zeroes the rest)
     int tile_stride;          // workgroup g serves tiles (g / 8) % ntiles, + tile_stride, ... (normally just one)
     int skip_grid;
     int* queues;              // [ntiles][QSTRIDE]
     double* partA;            // [B][nchA]
-    double* partB;            // [B][nchB]
+    double* partB;            // [B][nslot]: the grid integral, one partial per (walker, workgroup of its tile)
     // cells (lf_kernels.h: CELL_M): walkers flagged STAT_CELLS by lf_prepare are summed over them instead of the sources
     const double* cells;      // [ncell][8] {x_c, S_0 .. S_6}
     const int* cc_start;      // [nchC] first cell of a cell chunk
     const int* cc_len;        // [nchC] its cells (<= 64: one per lane of a wave; the waves take one walker each)
     const int* cc_field;      // [nchC]
-    int nchC;                 // cell chunks: items nitB .. nitB + nchC - 1 of the tile's front queue (0: no cells)
-    double* partC;            // [B][nchC]
+    int nchC;                 // cell chunks (64 cells; 0: no cells)
+    double* partC;            // [B][nslot]: the cells' sums, likewise
     const int* wstat;         // [B]
 };
 
@@ -112,11 +110,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         __builtin_assume(nw >= 1 && nw <= PTW);
         int* __restrict__ q = fa.queues + tile * QSTRIDE;
         // next item of this tile: a node chunk while there are any (item = chunk), then a catalogue chunk of our XCD's
-        // queue, or of the next queue that still has some (item = nitB + chunk); -1 = the tile is done
-        const int nF = fa.nitB;                    // front items: the grid items (the cell chunks are dealt the same way, per wave)
-        // The front items all cost about the same (and with every walker on cells they are all there is): they are dealt
-        // STATICALLY, item i to the workgroup of rank i mod fgroup among those serving the tile - no claims, whose round
-        // trips (microseconds each, every workgroup of a tile on one counter) were most of a launch of small items.
+        // queue, or of the next queue that still has some; -1 = none left
+        // Cell chunks and grid chunks all cost about the same (and with every walker on cells they are all there is): they
+        // are dealt STATICALLY, chunk i to the workgroup of rank i mod fgroup among those serving the tile - no claims.
         // Only the source chunks - unequal, and only needed by walkers that cannot use the cells - are claimed from queues.
         int fgroup = 8, frank = (int)blockIdx.x & 7;
         if (fa.ntiles <= fa.tile_stride) {
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int lo = (int)(((long long)qq * fa.nchA) >> 3), hi = (int)(((long long)(qq + 1) * fa.nchA) >> 3);
                 if (hi <= lo) continue;
                 const int i = atomicAdd(q + 1 + qq, 1);
-                if (i < hi - lo) return nF + lo + i;
+                if (i < hi - lo) return lo + i;
             }
             return -1;
         };
@@ -149,7 +145,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         auto redeem = [&]() -> int {
             if (no_src) return -1;
             const int lo = (int)(((long long)myq * fa.nchA) >> 3), hi = (int)(((long long)(myq + 1) * fa.nchA) >> 3);
-            if (ticket < hi - lo) return nF + lo + ticket;
+            if (ticket < hi - lo) return lo + ticket;
             return grab();                        // our queue is empty: steal (the grid queue and ours just hand out misses)
         };
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
@@ -162,7 +158,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             if (u == 0) {
                 scell = m;
                 no_src = fa.nchC > 0 && m == (1 << nw) - 1;
-                if (frank >= nF) sitem[0] = grab();
+                sitem[0] = grab();
             }
         }
         // the tile's walker constants, all fields (64 B per (walker, field)), once
@@ -207,6 +203,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         // cells in flight while the current one is summed - and writes one partial per chunk from the DPP network.
         {
             const int v = wave_base >> 6;
+            // A wave adds up its lanes' values over ALL its chunks and reduces them once: one partial per (walker, workgroup)
+            // (the chunks are dealt statically, so the order of the sums is fixed by the launch geometry).
+            double acc = 0.0;
             if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && frank < fa.nchC) {       // (wave-uniform)
                 auto load_cells = [&](double (&d)[8], int cc) {
                     const int lane = fresh_tid() & 63;      // (made here: carried through the loop it is spilled in one instantiation)
@@ -229,34 +228,75 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     if (cc + fgroup < fa.nchC) load_cells(nx, cc + fgroup);
                     const WalkerK p = fetch(v, uni(fa.cc_field[cc]));
                     asm volatile("; LF_BEGIN cell items=1");
-                    double acc = cell_sum(cd, p, &tt);
+                    acc += cell_sum(cd, p, &tt);
                     asm volatile("; LF_END cell");
-                    const int ln = fresh_tid() & 63;
-                    if (CENSUS && kc.forms && ln == 0) atomicAdd(kc.forms + FORM_CELL, (unsigned long long)uni(fa.cc_len[cc]));
-                    acc = wave_sum_dpp(acc);      // lane 63: the wave's total
-                    if (ln == 63) fa.partC[(size_t)(w0 + v) * fa.nchC + cc] = acc;
+                    if (CENSUS && kc.forms && (fresh_tid() & 63) == 0) atomicAdd(kc.forms + FORM_CELL, (unsigned long long)uni(fa.cc_len[cc]));
                 }
             }
-        }
-        int fnext = frank;                        // this workgroup's next front item
-        int item;
-        if (fnext < nF) {
-            item = fnext;
-            fnext += fgroup;
-        } else {
-            item = sitem[0];
-        }
-        // after a front item: the next one of this workgroup's share, or - once - the first claim from the source queues
-        auto after_front = [&](int t) -> int {
-            if (fnext < nF) {
-                const int it = fnext;
-                fnext += fgroup;
-                return it;
+            if (fa.nchC > 0 && v < nw) {
+                acc = wave_sum_dpp(acc);          // lane 63: the wave's total
+                const int ln = fresh_tid() & 63;
+                double* __restrict__ row = fa.partC + (size_t)(w0 + v) * fa.nslot;
+                if (ln == 63) row[frank] = acc;
+                if (frank == 0)
+                    for (int i = fgroup + ln; i < fa.nslot; i += 64) row[i] = 0.0;       // (slots of workgroups this tile does not have)
             }
-            if (t == 0) sitem[0] = grab();
-            __syncthreads();
-            return sitem[0];
-        };
+        }
+        // ---- the grid integral (piece B), the same way: 64 nodes per chunk, one WALKER PER WAVE (lane = node), every wave
+        // on its own through this workgroup's share of the chunks - no LDS, no barrier, one partial per (walker, chunk) from
+        // the DPP network.  (As workgroup-wide items of 512 nodes x 4 walkers, with two barriers and an LDS reduction each,
+        // the grid took 16 us of a 34-us launch for 6 us worth of instructions.)
+        {
+            const int v = wave_base >> 6;
+            const int nch64 = fa.nchB;            // chunks of 64 nodes
+            double bsum = 0.0;
+            if (v < nw && frank < nch64) {
+                const double* __restrict__ sc = wsc + v * 8;
+                const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (v * MAXF) * 8 + 4));
+                // per-field constants of this walker as the grid forms expect them: r[RF(f, F_CA)], r[RF(f, F_V)]
+                const double* __restrict__ r = wfc + v * MAXF * 8 - 8;   // RF(f, slot) = 8 + 8 f + slot
+                double vmin = r[RF(0, F_V)];
+                for (int f = 1; f < kc.nf; ++f) vmin = fmin(vmin, r[RF(f, F_V)]);
+                vmin = uni(vmin);
+                const double alphaC = uni(sc[R_ALPHAC]);
+                // (source-sharded ranks split the grid: this context integrates the chunks c with c % parts == part)
+                auto mine = [&](int c) { return mode != MODE_SKIP && !(kc.grid_parts > 1 && c % kc.grid_parts != kc.grid_part); };
+                struct Node {
+                    double G, PG, W, a3, a4;
+                };
+                auto load_nodes = [&](int c) -> Node {
+                    const int lane = fresh_tid() & 63;
+                    const int g = min(c * 64 + lane, na.nnodes - 1);
+                    return Node{na.G[g], na.PG[g], c * 64 + lane < na.nnodes ? na.W[g] : 0.0, na.a3[g], na.a4[g]};
+                };
+                Node nx = load_nodes(frank);      // the next chunk's nodes are in flight while the current one is summed
+#pragma unroll 1
+                for (int c = frank; c < nch64; c += fgroup) {
+                    const Node nd = nx;
+                    if (c + fgroup < nch64) nx = load_nodes(c + fgroup);
+                    if (mine(c)) {
+                        const double a4min = uni(na.a4min64[c]);       // the chunk's faintest node, for the bright form of the field sum
+                        const double T = fexp_c(fma(uni(sc[R_C1]), nd.G - uni(sc[R_LSTAR]), uni(sc[R_C0])) - nd.PG * uni(sc[R_Q]), &tab);
+                        const bool bright = kc.specialise && alphaC > 0.0 && a4min * vmin > 37.5;
+                        if (CENSUS && kc.forms && (fresh_tid() & 63) == 0)
+                            atomicAdd(kc.forms + (bright ? FORM_NODE_BRIGHT : FORM_NODE_GENERAL),
+                                      (unsigned long long)(min(64, na.nnodes - c * 64) * kc.nf));
+                        const double s = field_sum_nf(kc, r, alphaC, nd.a3, nd.a4, &tab, bright);
+                        bsum = fma(nd.W * T, s, bsum);
+                    }
+                }
+            }
+            if (nch64 > 0 && v < nw) {
+                bsum = wave_sum_dpp(bsum);        // lane 63: the wave's total
+                const int ln = fresh_tid() & 63;
+                double* __restrict__ row = fa.partB + (size_t)(w0 + v) * fa.nslot;
+                if (ln == 63) row[frank] = bsum;
+                if (frank == 0)
+                    for (int i = fgroup + ln; i < fa.nslot; i += 64) row[i] = 0.0;
+            }
+        }
+        // ---- what is left are the source chunks, for walkers that cannot use the cells: claimed from the per-XCD queues
+        int item = sitem[0];
 #pragma unroll 1
         while (item >= 0) {
 #ifdef LF_STAMPS
@@ -266,9 +306,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #endif
             __syncthreads();                      // [D] the previous item's reduction has read `red` (and sitem)
             int t = fresh_tid();
-            if (__builtin_expect(item >= nF, 1)) {
+            {
                 // ================= catalogue chunk: piece A =================
-                const int c = item - nF;
+                const int c = item;
                 // (wave-uniform by construction; said so, or they sit - and are spilled - in vector registers)
                 const int s0 = uni(sa.chunk_start[c]), n = uni(sa.chunk_len[c]), fld = uni(sa.chunk_field[c]);
                 // (kamax: the largest alpha_C key for which THIS WAVE's lanes fit one table piece each)
@@ -411,43 +451,6 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 t = fresh_tid();
                 reduce_store512(red, 0, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
                 item = sitem[0];
-            } else {
-                // ================= node chunk: piece B =================
-                int sub = 0, c = item;                                                             // walker sub-tile, chunk
-                while (c >= fa.nchB) {            // (item = sub * nchB + c with sub < nsplit <= 8: a few scalar subtractions; a
-                    c -= fa.nchB;                 // division by a run-time value leaves a reciprocal to be hoisted and spilled)
-                    ++sub;
-                }
-                const int wlo = sub * fa.wpn, whi = min(wlo + fa.wpn, nw);                         // (empty for a ragged last tile)
-                const bool valid = c * PB + t < na.nnodes;
-                const int g = min(c * PB + t, na.nnodes - 1);
-                const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0, a3 = na.a3[g], a4 = na.a4[g];
-                const double a4min = fmin(na.a4min[2 * c], na.a4min[min(2 * c + 1, (na.nnodes + BLOCK - 1) / BLOCK - 1)]);   // wave-uniform
-                const int nodes_here = min(PB, na.nnodes - c * PB);
-#pragma unroll 1
-                for (int w = wlo; w < whi; ++w) {
-                    const double* __restrict__ sc = wsc + w * 8;
-                    const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (w * MAXF) * 8 + 4));
-                    double val = 0.0;
-                    if (mode != MODE_SKIP) {      // outside the prior: not evaluated
-                        const double T = fexp_c(fma(uni(sc[R_C1]), G - uni(sc[R_LSTAR]), uni(sc[R_C0])) - PG * uni(sc[R_Q]), &tab);
-                        const double alphaC = uni(sc[R_ALPHAC]);
-                        // per-field constants of this walker as the grid forms expect them: r[RF(f, F_CA)], r[RF(f, F_V)]
-                        const double* __restrict__ r = wfc + w * MAXF * 8 - 8;   // RF(f, slot) = 8 + 8 f + slot
-                        double vmin = r[RF(0, F_V)];
-                        for (int f = 1; f < kc.nf; ++f) vmin = fmin(vmin, r[RF(f, F_V)]);
-                        const bool bright = kc.specialise && alphaC > 0.0 && a4min * uni(vmin) > 37.5;
-                        if (CENSUS && kc.forms && t == 0)
-                            atomicAdd(kc.forms + (bright ? FORM_NODE_BRIGHT : FORM_NODE_GENERAL), (unsigned long long)(nodes_here * kc.nf));
-                        const double s = field_sum_nf(kc, r, alphaC, a3, a4, &tab, bright);
-                        val = W * T * s;
-                    }
-                    red[w * PB + t] = val;
-                }
-                __syncthreads();                  // [C]
-                t = fresh_tid();
-                reduce_store512(red, wlo, whi, fa.partB, (size_t)fa.nchB, w0, c, t);
-                item = after_front(t);
             }
 #ifdef LF_STAMPS
             ++nitems_done;

@@ -955,6 +955,7 @@ struct NodeArrays {
     const double* a3;     // FREE: logf on the grid                ZEVOL: zarr[k]
     const double* a4;     // FREE: 10^(logf_grid + 17)             ZEVOL: zarr[k]^2
     const double* a4min;  // FREE: per chunk of 256 nodes, the smallest a4 (for the bright form, field_sum_bright)
+    const double* a4min64;   // ... per chunk of 64 nodes (lf_free)
     int nnodes;
 };
 

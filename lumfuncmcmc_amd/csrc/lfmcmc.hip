@@ -72,12 +72,11 @@ struct lf_ctx {
     int num_cu = 0;
     // device tables
     double *d_lum = nullptr, *d_a1 = nullptr, *d_P = nullptr, *d_U = nullptr;
-    double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr, *d_a4min = nullptr;
+    double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr, *d_a4min = nullptr, *d_a4min64 = nullptr;
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     std::map<int, ChunkTable> chunks_free;   // the persistent FREE kernel's (lf_free.h): 512 ST sources per chunk, lanes of ST
     int64_t opt_persistent = 1;         // FREE: 1 = lf_free (persistent 512-thread workgroups) for catalogues that fill it
     int64_t opt_free_st = 0;            // lf_free: sources per lane, 0 = chosen from N and B, else 2 / 4 / 8 (tuning runs)
-    int64_t opt_node_split = 0;         // lf_free: grid items per node chunk and walker tile, 0 = chosen, else 1 / 2 / 4 / 8
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
     int64_t opt_taper = 0;              // 1: quarter-size walker tiles for the last ~1/8 of the walkers (second pass over the catalogue)
@@ -456,27 +455,29 @@ void launch_main(lf_ctx* c, int gi, dim3 grid, lf::Tiling tl, int ntilesB, int t
 
 // FREE variant, real catalogue, catalogues large enough to fill it: prepare -> lf_free (persistent 512-thread workgroups,
 // pieces A and B, lf_free.h) -> finalize
-// Item sizes of the persistent FREE kernel (lf_free.h).  Sources per lane: 8 (the table lookup is shared by 8 terms)
-// once the catalogue gives 4096-source chunks enough to go round, else 4; a node chunk is served in two items of four
-// walkers each (measured on a warmed-up device, 128 rows, us: N = 1e6 113.4 -> 111.6, 5e5 74.4 -> 72.4 with ST = 8;
-// N = 2.5e5 58.1 -> 55.7, 1e5 45.7 -> 40.2 going from ST = 8 to 4).  free_st / node_split override (tuning runs).
+// Source-chunk size of the persistent FREE kernel (lf_free.h), for walkers that are summed over the sources: sources per
+// lane 8 (the table lookup is shared by 8 terms) once the catalogue gives 4096-source chunks enough to go round, else 4
+// (measured on a warmed-up device, cells off, 128 rows, us: N = 2.5e5 58.1 -> 55.7, 1e5 45.7 -> 40.2 going from ST = 8
+// to 4).  free_st overrides (tuning runs).
 struct FreeShape {
-    int st, nsplit;
-    int64_t items_per_tile;      // catalogue chunks + grid items
+    int st;
+    int64_t items_per_tile;      // source chunks + grid chunks of 512 nodes' worth (the old item count: the crossover rule
+                                 // for contexts without cells was measured in these units)
 };
 FreeShape free_shape(const lf_ctx* c) {
     using namespace lf;
     FreeShape fs;
     const int64_t chunks8 = (c->N + 8 * (int64_t)PB - 1) / (8 * (int64_t)PB);
     fs.st = c->opt_free_st ? (int)c->opt_free_st : (chunks8 >= 74 ? 8 : 4);
-    fs.nsplit = c->opt_node_split ? (int)c->opt_node_split : 2;
     const int64_t nchB = c->opt_skip_grid ? 0 : (c->nnodes + PB - 1) / PB;
-    fs.items_per_tile = (c->N + (int64_t)PB * fs.st - 1) / ((int64_t)PB * fs.st) + nchB * fs.nsplit;
+    fs.items_per_tile = (c->N + (int64_t)PB * fs.st - 1) / ((int64_t)PB * fs.st) + nchB * 2;
     return fs;
 }
 
+// The number of groups of 8 workgroups (one per XCD under round-robin placement) lf_free<ST> is launched with: no more
+// than the chip holds at once, no more than there are items.
 template <int ST>
-void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa, const lf::NodeArrays& na, lf::FreeArgs fa, hipStream_t s) {
+int free_groups(lf_ctx* c, int slot, int ntiles, int nchA, int nchB, int nchC) {
     using namespace lf;
     if (c->slots_free[slot] == 0) {
         int nb = 0;
@@ -488,12 +489,15 @@ void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa
             std::fprintf(stderr, "lf_free<%d>: %d workgroups per CU (occupancy API), %d VGPRs, %zu B LDS\n", ST, nb, at.numRegs, at.sharedSizeBytes);
         }
     }
-    // groups of 8 workgroups (one per XCD under round-robin placement) per tile; no more than the chip holds at once,
-    // no more than there are items
-    const int64_t per_tile = ((int64_t)fa.nchA + fa.nitB + fa.nchC + 7) / 8;
-    const int64_t g8 = std::max<int64_t>(1, std::min<int64_t>(c->slots_free[slot] / 8, (int64_t)ntiles * std::max<int64_t>(per_tile, 1)));
-    fa.tile_stride = (int)g8;
-    const dim3 grid((unsigned)(8 * g8));
+    const int64_t per_tile = ((int64_t)nchA + nchB + nchC + 7) / 8;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(c->slots_free[slot] / 8, (int64_t)ntiles * std::max<int64_t>(per_tile, 1)));
+}
+
+template <int ST>
+void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa, const lf::NodeArrays& na, lf::FreeArgs fa, hipStream_t s) {
+    // (fa.nslot is set by the caller from free_groups(), which is also what the grid is made of here)
+    using namespace lf;
+    const dim3 grid((unsigned)(8 * fa.tile_stride));
     const int info[8] = {ST, PTW, PTW, 2, (int)grid.x, fa.nchA, fa.nchB, B};
     std::memcpy(c->last_launch, info, sizeof(info));
     if (c->kc.forms) hipLaunchKernelGGL((lf_free<ST, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
@@ -510,10 +514,13 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     int rc = get_chunks(c, c->chunks_free, c->field_ind, PB * st, &ct, c->h_x.data(), st);
     if (rc != LF_OK) return rc;
     const int nchA = ct->n;
-    const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + PB - 1) / PB;
-    const int nsplit = fs.nsplit;
+    const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + 63) / 64;        // chunks of 64 nodes: a wave's lanes
     const int nchC = c->kc.cells ? c->ncchunk : 0;
-    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * std::max(nchC, 1));
+    const int g8 = st == 8 ? free_groups<8>(c, slot, ntiles, nchA, nchB, nchC)
+                 : st == 4 ? free_groups<4>(c, slot, ntiles, nchA, nchB, nchC) : free_groups<2>(c, slot, ntiles, nchA, nchB, nchC);
+    // the grid's and the cells' partial sums: one per (walker, workgroup serving the walker's tile)
+    const int nslot = ntiles <= g8 ? 8 * ((g8 + ntiles - 1) / ntiles) : 8;
+    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * nslot, (size_t)B * nslot);
     if (rc != LF_OK) return rc;
     if (ntiles * QSTRIDE > c->cap_queue) {
         LF_HIP(c, hipDeviceSynchronize());
@@ -532,8 +539,8 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
                            c->d_wstat, c->d_wmode, c->d_wbase, (int*)nullptr, c->d_queue, ntiles * QSTRIDE);
     }
     const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
-    const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
-    FreeArgs fa{B, ntiles, nchA, nchB, nsplit, nchB * nsplit, PTW / nsplit, 1, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
+    const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_a4min64, c->nnodes};
+    FreeArgs fa{B, ntiles, nchA, nchB, nslot, g8, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
                 c->d_cells, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat};
     {
         Prof p(c, s, 1);
@@ -545,8 +552,9 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     }
     {
         Prof p(c, s, 3);
-        hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           nchC > 0 ? (const double*)c->d_partR : (const double*)nullptr, nchC, (int)STAT_CELLS, c->d_wstat, c->d_wbase, B, ap,
+        const int nB = nchB > 0 ? nslot : 0, nC = nchC > 0 ? nslot : 0;
+        hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nB, nB,
+                           nC > 0 ? (const double*)c->d_partR : (const double*)nullptr, nC, (int)STAT_CELLS, c->d_wstat, c->d_wbase, B, ap,
                            d_out, d_outA, d_outB, (int*)nullptr);
     }
     LF_HIP(c, hipGetLastError());
@@ -635,7 +643,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         rs.nchD = nchD;
         rs.nresc = nresc;
     }
-    NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
+    NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_a4min64, c->nnodes};
     {
         Prof p(c, s, 1);
         int tw = geo.tw, twb = geo.twb;
@@ -909,7 +917,7 @@ void free_ctx(lf_ctx* c) {
         for (int* b : gi_)
             if (b) hipFree(b);
     }
-    double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min,
+    double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_a4min64,
                       c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
     for (double* b : bufs)
         if (b) hipFree(b);
@@ -1146,6 +1154,14 @@ int build(lf_ctx* c, const lf_desc* d) {
             a4min[ch] = d->variant == LF_FREE ? m : 0.0;
         }
         if ((rc = upload(c, &c->d_a4min, a4min.data(), a4min.size())) != LF_OK) return rc;
+        // ... and per chunk of 64 nodes (lf_free: a wave's lanes)
+        std::vector<double> a4min64((nn + 63) / 64, 0.0);
+        for (size_t ch = 0; ch < a4min64.size(); ++ch) {
+            double m = HUGE_VAL;
+            for (size_t g = ch * 64; g < std::min(nn, (ch + 1) * 64); ++g) m = std::isnan(a4[g]) ? 0.0 : std::fmin(m, a4[g]);
+            a4min64[ch] = d->variant == LF_FREE ? m : 0.0;
+        }
+        if ((rc = upload(c, &c->d_a4min64, a4min64.data(), a4min64.size())) != LF_OK) return rc;
     }
     {
         hipDeviceProp_t prop;
@@ -1458,14 +1474,6 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     if (std::strcmp(key, "cells") == 0) {
         c->opt_cells = value != 0;
         c->kc.cells = c->opt_cells && c->ncell > 0;
-        return LF_OK;
-    }
-    if (std::strcmp(key, "node_split") == 0) {
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) {
-            c->err = "node_split must be 0 (auto), 1, 2, 4 or 8";
-            return LF_ERR_ARG;
-        }
-        c->opt_node_split = value;
         return LF_OK;
     }
     if (std::strcmp(key, "persistent") == 0) {

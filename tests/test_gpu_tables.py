@@ -193,3 +193,32 @@ def test_cells_are_not_used_when_they_cannot_be():
     ctx.close()
     assert fc["cell"] == 0 and fc["table"] + fc["table_noexp"] > 0, fc
     compare_rows(got, ref, inp, th, 1e-12)
+
+
+@pytest.mark.parametrize("cells", [1, 0])
+def test_source_shards_through_the_persistent_kernel_add_up(cells):
+    """Source-sharded ranks (dist.SourceShardedLnProb) in one process: three contexts hold a third of every field's
+    sources each and a third of the grid chunks ("grid_share"); their lnprob values add up to the unsharded one - through
+    lf_free, with and without cells (the grid must be integrated once, not once per shard)."""
+    from lumfuncmcmc_amd.capi import LFContext
+    from lumfuncmcmc_amd.dist import shard_sources
+    inp = make_inputs("free", 240000, seed=61)
+    th = _rows(24, 62)
+    th[2, 0] = 40.2
+    full = LFContext(inp)
+    full.set_option("persistent", 2)
+    full.set_option("cells", cells)
+    ref = full.lnprob_batch(th)
+    full.close()
+    tot = np.zeros(len(th))
+    for part in range(3):
+        ctx = LFContext(shard_sources(inp, part, 3))
+        ctx.set_option("persistent", 2)
+        ctx.set_option("cells", cells)
+        ctx.set_option("grid_share", part + 65536 * 3)
+        tot = tot + ctx.lnprob_batch(th)
+        assert ctx.last_launch()["kernel"].startswith("lf_free")
+        ctx.close()
+    assert np.array_equal(np.isinf(tot), np.isinf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(tot[fin], ref[fin], rtol=1e-13)
