@@ -269,7 +269,7 @@ def fence_light(leg):
     torch.cuda.current_stream().synchronize()
 
 
-def timed(leg, fence, warmup, steps, profile_level, agree=None):
+def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1):
     """W warm-up + settle steps, then `steps` timed steps between two fences.  Returns (seconds, kernel times, last out)."""
     import gc
     for i in range(warmup):
@@ -299,6 +299,11 @@ def timed(leg, fence, warmup, steps, profile_level, agree=None):
             fence_light(leg)
     fence()
     leg.ctx.kernel_times()                      # clear
+    # The event pairs that time the kernel are barrier packets: a bracketed launch no longer overlaps the tail of the one
+    # before it (tools/call_period.py: 39.7 us per evaluation without events, 47.3 us with a pair around every lf_main).
+    # So only every `profile_every`-th evaluation of the timed steps is bracketed - still live, still in the timed
+    # region, on the launch stream; "launches" in the roofline object is the number that were.
+    leg.ctx.set_option("profile_every", max(int(profile_every), 1))
     leg.ctx.set_profiling(profile_level)
     t0 = time.perf_counter()
     dbg = []
@@ -311,6 +316,7 @@ def timed(leg, fence, warmup, steps, profile_level, agree=None):
     if os.environ.get("LF_BENCH_DEBUG"):
         print("debug: host time after each step (ms):", " ".join("%.2f" % (x * 1e3) for x in dbg[:8]), "fence done %.2f" % (dt * 1e3), file=sys.stderr)
     leg.ctx.set_profiling(0)
+    leg.ctx.set_option("profile_every", 1)
     return dt, leg.ctx.kernel_times(), out
 
 
@@ -369,7 +375,9 @@ def roofline_of(args, leg, model, kt, dt):
     ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
     return {"bound": "valu_fp64", "kernel": kernel, "achieved": ach_tf,
             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
-            "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches, "measured_on": "rank 0",
+            "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
+            "launches_timed": "every %d-th of the timed region's %d, HIP events on the launch stream" % (max(args.profile_every, 1), 2 * args.steps),
+            "measured_on": "rank 0",
             "launch": launch, "terms_per_launch": terms,
             "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
             "items_per_launch_by_form": cnt,
@@ -411,6 +419,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="bracket only every n-th evaluation of the timed steps with events (each pair stalls the stream ~8 us)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -472,7 +482,7 @@ def main():
 
     leg = Leg(args, model, dev, local, world, rank, Wtot, shard)
     ctx, ndim, half = leg.ctx, leg.ndim, leg.half
-    dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level, agree=reduce_max)
+    dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level, agree=reduce_max, profile_every=args.profile_every)
     dt = reduce_max(dt)
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), "non-finite lnprob in the timed workload"
     step, theta_all, nblk = leg.step, leg.theta_all, leg.nblk

@@ -111,6 +111,9 @@ struct lf_ctx {
     bool any_enqueued = false;
     // profiling
     int profiling = 0;   // 0 off, 1 lf_main only, 2 every launch
+    int64_t opt_profile_every = 1;      // ... of every n-th evaluation only (an event pair costs the stream ~4 us: it drains the queue)
+    int64_t prof_tick = 0;
+    bool prof_this = true;              // (this evaluation is one of them)
     std::vector<EventPair> events;
     double acc_ms[4] = {0, 0, 0, 0};
     int64_t acc_n[4] = {0, 0, 0, 0};
@@ -389,7 +392,7 @@ struct Prof {
     int kind;
     EventPair ep{};
     bool on;
-    Prof(lf_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling >= 2 || (c_->profiling == 1 && k == 1)) {
+    Prof(lf_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->prof_this && (c_->profiling >= 2 || (c_->profiling == 1 && k == 1))) {
         if (on) {
             hipEventCreate(&ep.a);
             hipEventCreate(&ep.b);
@@ -533,6 +536,7 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->any_enqueued = true;
+    c->prof_this = c->profiling > 0 && (c->prof_tick++ % c->opt_profile_every) == 0;
     {
         Prof p(c, s, 0);
         hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
@@ -616,6 +620,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->any_enqueued = true;
+    c->prof_this = c->profiling > 0 && (c->prof_tick++ % c->opt_profile_every) == 0;
 
     {
         Prof p(c, s, 0);
@@ -1461,6 +1466,11 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             LF_HIP(c, hipMemset(c->d_forms, 0, lf::FORM_COUNT * sizeof(unsigned long long)));
         }
         c->kc.forms = value != 0 ? c->d_forms : nullptr;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "profile_every") == 0) {
+        c->opt_profile_every = value < 1 ? 1 : value;
+        c->prof_tick = 0;
         return LF_OK;
     }
     if (std::strcmp(key, "free_st") == 0) {
