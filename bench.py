@@ -349,8 +349,17 @@ def roofline_of(args, leg, model, kt, dt):
     used = sorted({(2 * i) % leg.nblk for i in range(args.steps)} | {(2 * i + 1) % leg.nblk for i in range(args.steps)})
     launch = leg.ctx.last_launch()
     kernel, forms = isa_counts(launch, variant)
-    cnt = census(leg, used) if variant == "free" else {}
-    if variant == "free":
+    cnt = census(leg, used) if variant in ("free", "zevol") else {}
+    if variant == "zevol":
+        # the z-evolving kernel's census: "cell" = (walker, cell in redshift) pairs, "table" = terms of the local form (one
+        # exponential per lane of z-neighbours), "general" = per-source exponentials, "node_general" = grid nodes
+        name = {"cell": "zcell", "table": "zevol", "general": "zevol_direct", "node_general": "znode"}
+        zero = {"flops_per_item": 0.0, "cycles_per_item": 0.0}
+        src_flops = sum(cnt.get(f, 0.0) * forms.get(name[f], zero)["flops_per_item"] for f in ("cell", "table", "general"))
+        src_cycles = sum(cnt.get(f, 0.0) * forms.get(name[f], zero)["cycles_per_item"] for f in ("cell", "table", "general"))
+        grid_flops = cnt.get("node_general", 0.0) * forms.get("znode", zero)["flops_per_item"]
+        grid_cycles = cnt.get("node_general", 0.0) * forms.get("znode", zero)["cycles_per_item"]
+    elif variant == "free":
         src_flops = sum(cnt.get(f, 0.0) * forms[f]["flops_per_item"] for f in SOURCE_FORMS if f in forms)
         src_cycles = sum(cnt.get(f, 0.0) * forms[f]["cycles_per_item"] for f in SOURCE_FORMS if f in forms)
         grid_flops = sum(cnt.get(f, 0.0) * forms[f]["flops_per_item"] for f in NODE_FORMS if f in forms)

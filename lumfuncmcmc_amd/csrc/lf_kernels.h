@@ -49,6 +49,17 @@ enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4,      // SLOW: some fie
 // (tests/test_tables_cpu.py recomputes that bound from the tables' coefficients).
 constexpr int CELL_M = 6;
 constexpr double CELL_RHO_G = 5.0e-3, CELL_RHO_H = 1.0e-3;
+// ZEVOL has cells too, in REDSHIFT.  What is left of the term per source is v_i = 10^(lum_i - L*(z_i)) with L* a
+// quadratic aL z^2 + bL z + cL of the walker (lumfuncmcmc_z.py:66): about a cell's midpoint z_c, with d = z_i - z_c,
+//     v_i = 10^(lum_i - LREF) * 10^(LREF - L*(z_c)) * exp(a d + b d^2),   a = -ln10 L*'(z_c),  b = -ln10 aL
+// and exp(a d + b d^2) = sum_j c_j d^j with c_0 = 1, j c_j = a c_(j-1) + 2 b c_(j-2): an entire function, so the sum over
+// the cell is 10^(LREF - L*(z_c)) sum_j c_j S_j with the WEIGHTED power sums S_j = sum_i 10^(lum_i - LREF) d_i^j - all
+// weights positive, so a relative error of the series is a relative error of the cell's sum.  Cells are at most
+// 2 rho wide, and a walker takes them when |a| rho <= ZCELL_X1 over the field's redshifts and |b| rho^2 <= ZCELL_X2
+// (lf_prepare): the orders above CELL_M then sum to less than 1e-17 (tests/test_tables_cpu.py recomputes the bound from
+// the majorant series exp(X1 t + X2 t^2)).  rho (KConst::zcell_rho) is chosen when the context is made, at most
+// ZCELL_RHO and small enough that EVERY walker inside the prior box of L1..L3 passes (lfmcmc.hip: zcell_rho_for_box).
+constexpr double ZCELL_RHO = 1.0e-3, ZCELL_X1 = 6.0e-3, ZCELL_X2 = 1.0e-5;
 
 // walker record, FREE / FIXCOMP: walker scalars ...
 enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4 };
@@ -71,7 +82,8 @@ enum { Z_AL = 0, Z_BL = 1, Z_CL = 2, Z_AP = 3, Z_BP = 4, Z_CP = 5, Z_C1 = 6 };
 struct KConst {
     int variant, fix_sch_al, nf, S, ndim;
     int specialise;           // 1: chunk-level term specialisation (term_free_noexp); 0 for A/B runs
-    int cells;                // FREE: 1 = the catalogue's cells exist and lf_prepare may flag walkers STAT_CELLS
+    int cells;                // FREE, ZEVOL: 1 = the catalogue's cells exist and lf_prepare may flag walkers STAT_CELLS
+    double zcell_rho;         // ZEVOL: half the largest width of a cell in redshift (ZCELL_RHO below)
     int kf_first[MAXF], kf_last[MAXF];   // FREE: keys (floor / ceil) of each field's faintest / brightest source
     int grid_part, grid_parts; // source-sharded ranks split piece B too: this context integrates the node chunks c with
                               // c % grid_parts == grid_part (the others contribute 0); 0 / 1 = the whole grid
@@ -322,6 +334,9 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
             // chunk's key is 0 and the form is not taken)
             const double s0 = fabs(fma(2.0 * aL, kc.z_lo[f], bL)), s1 = fabs(fma(2.0 * aL, kc.z_hi[f], bL));
             r[RF(f, 0)] = LF_LN10 * (fmax(s0, s1) + fabs(aL) * (1.0 / 128.0));
+            // the field's cells in redshift can stand for its sources (ZCELL_RHO above; NaN coefficients fail the test)
+            cell_ok = kc.nsrc[f] == 0 || (LF_LN10 * fmax(s0, s1) * kc.zcell_rho <= ZCELL_X1 &&
+                                          LF_LN10 * fabs(aL) * kc.zcell_rho * kc.zcell_rho <= ZCELL_X2);
         }
         if (has_f && kc.nsrc[f] > 0) {
             double lsmn, lsmx, phmn, phmx;
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     const int slow = group8_or(has_f && m == MODE_SLOW ? 1 : 0);
     // cells: only walkers whose every field is FAST and inside the tables (all the others are rare, and summed per source)
     const int nocell = group8_or(has_f && !(cell_ok && (m == MODE_FAST || kc.nsrc[f] == 0)) ? 1 : 0);
-    const int cells = kc.cells && kc.variant == LF_FREE && nqueue > 0 && !bad && !neginf && !nocell;
+    const int cells = kc.cells && (kc.variant == LF_FREE ? nqueue > 0 : kc.variant == LF_ZEVOL) && !bad && !neginf && !nocell;
     if (live && has_f) wmode[((size_t)w * MAXF + f) * WM + M_MODE] = m;
     if (live && f == 0) {
         wbase[w] = base;
@@ -698,7 +713,10 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
                 const WZ wz = nz;
                 nz = WZ{rn[Z_AL], rn[Z_BL], rn[Z_CL], rn[Z_AP], rn[Z_BP], rn[Z_CP], rn[Z_C1], rn[RF(fld, 0)]};
                 if (mode < MODE_SKIP) {
-                if (ZLOCAL && kc.specialise && wz.mslope <= 6.0e-3 * zwidth_inv) {      // (wave-uniform)
+                const bool zlocal = ZLOCAL && kc.specialise && wz.mslope <= 6.0e-3 * zwidth_inv;      // (wave-uniform)
+                // (census, ZEVOL: "table" counts the terms of the local form, "general" the per-source exponentials)
+                if (!CMP && kc.forms && tid == 0) atomicAdd(kc.forms + (zlocal ? FORM_TABLE : FORM_GENERAL), (unsigned long long)n);
+                if (zlocal) {
                     asm volatile("; LF_BEGIN zevol items=%0" ::"n"(ST));
                     const double Lc = quad_nofma(wz.aL, wz.bL, wz.cL, zc, uu[0]);
                     const double Hc = fexp_t(LF_LN10 * (LF_LREF - Lc), &tab);
@@ -1072,7 +1090,10 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
         } else {
             const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1], 0.0};
             double v;
+            if (kc.forms && tid == 0) atomicAdd(kc.forms + FORM_NODE_GENERAL, (unsigned long long)min(BLOCK, na.nnodes - c * BLOCK));
+            asm volatile("; LF_BEGIN znode items=1");
             val = W * fexp_c(lnT_zevol<true>(wz, G, a3, a4, v, &tab), &tab);
+            asm volatile("; LF_END znode");
         }
         red[w * BLOCK + tid] = val;
     }
@@ -1192,12 +1213,69 @@ struct Rescue {
     int nchD, nresc;
 };
 
+// ZEVOL on the real catalogue: `nchC` chunks of up to BLOCK cells in redshift (ZCELL_RHO above; one field per chunk).
+// Walkers flagged STAT_CELLS by lf_prepare are summed over them by workgroups appended to the launch, into
+// partC[w][chunk], which lf_finalize then takes instead of partA; a per-source workgroup whose walkers all carry the
+// flag leaves at once.
+struct ZCells {
+    const double* cells;        // [ncell][8] {z_c, S_0 .. S_6}
+    const int* cc_start;        // [nchC]
+    const int* cc_len;
+    const int* cc_field;
+    int nchC;                   // 0: no cells
+    double* partC;              // [B][nchC]
+    const int* wstat;           // [B]
+};
+
+// one item: cell chunk cc x walkers w0 .. w0+nw-1 (a thread = a cell)
+template <int TW>
+__device__ __forceinline__ void zcell_body(const KConst& kc, const ZCells& zc, const double* __restrict__ wrec, int cc, int w0, int nw,
+                                           const MathTables& tab, double* __restrict__ red) {
+    const int tid = threadIdx.x;
+    const int c0 = zc.cc_start[cc], ncl = zc.cc_len[cc];
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(zc.cells + (size_t)(c0 + min(tid, ncl - 1)) * 8);
+    double cd[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double2 a = src[k];
+        cd[2 * k] = tid < ncl || k == 0 ? a.x : 0.0;       // (z_c always; a thread past the end: every power sum 0)
+        cd[2 * k + 1] = tid < ncl ? a.y : 0.0;
+    }
+    const double zc2 = cd[0] * cd[0];
+    if (kc.forms && tid == 0) atomicAdd(kc.forms + FORM_CELL, (unsigned long long)ncl * nw);
+#pragma unroll 1
+    for (int w = 0; w < nw; ++w) {
+        const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+        const double aL = uni(r[Z_AL]), bL = uni(r[Z_BL]), cL = uni(r[Z_CL]);
+        asm volatile("; LF_BEGIN zcell items=1");
+        const double Lc = quad_nofma(aL, bL, cL, cd[0], zc2);
+        const double Hc = fexp_c(LF_LN10 * (LF_LREF - Lc), &tab);
+        const double b2 = -2.0 * LF_LN10 * aL;                              // 2 b
+        const double a = fma(b2, cd[0], -LF_LN10 * bL);                     // -ln10 L*'(z_c)
+        // c_j by the recurrence, the sum with the small terms kept apart from S_0 (the cell's total weight)
+        double cm2 = 1.0, cm1 = a;
+        double tail = 0.0;
+        double head = fma(cm1, cd[2], cd[1]);                               // S_0 + c_1 S_1
+#pragma unroll
+        for (int j = 2; j <= CELL_M; ++j) {
+            const double cj = fma(a, cm1, b2 * cm2) * (1.0 / j);
+            tail = fma(cj, cd[1 + j], tail);
+            cm2 = cm1;
+            cm1 = cj;
+        }
+        red[w * BLOCK + tid] = -Hc * (head + tail);                         // everything else of the term is in wbase
+        asm volatile("; LF_END zcell");
+    }
+    __syncthreads();
+    reduce_store(red, nw, zc.partC, (size_t)zc.nchC, w0, cc);
+}
+
 template <int VARIANT, int ST, int TW, int TWB, bool CMP>
 __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeArrays na,
                                                  const double* __restrict__ wrec, const int* __restrict__ wmode,
                                                  int B, Tiling tl, int nchA, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
-                                                 double* __restrict__ partB, int strideB, Rescue rs, GridC gc) {
+                                                 double* __restrict__ partB, int strideB, Rescue rs, GridC gc, ZCells zc) {
     __shared__ MathTables tab;
     __shared__ __attribute__((aligned(16))) double red[(TW > TWB ? TW : TWB) * BLOCK];
     __shared__ double Tw[CMP ? GRIDC_MAX_S : 1];
@@ -1216,8 +1294,35 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
             return;
         }
     }
+    constexpr bool ZC = VARIANT == LF_ZEVOL && !CMP;
+    const int nsrc_wg = nchA * (tl.ntiles + tl.ntiles_s);
+    if (ZC && zc.nchC > 0 && id >= nblkB && id < nblkB + nsrc_wg) {
+        // a per-source workgroup whose walkers are all summed over the cells has nothing to do: leave before the prologue
+        // (the same tile arithmetic as below)
+        const int sid = id - nblkB, nbig_ = nchA * tl.ntiles;
+        int w0_, nw_;
+        if (sid < nbig_) {
+            const int wg = xcd_renumber(sid, nbig_);
+            w0_ = (wg % tl.ntiles) * tl.tw;
+            nw_ = min(tl.tw, tl.B1 - w0_);
+        } else {
+            const int wg = xcd_renumber(sid - nbig_, nchA * tl.ntiles_s);
+            w0_ = tl.B1 + (wg % tl.ntiles_s) * tl.tws;
+            nw_ = min(tl.tws, B - w0_);
+        }
+        const int lane = threadIdx.x & 63;
+        const int flagged = lane < nw_ ? (zc.wstat[w0_ + lane] & STAT_CELLS) : STAT_CELLS;      // (tiles are at most 16 walkers)
+        if (__builtin_amdgcn_ballot_w64(flagged == 0) == 0) return;                             // (the same in every wave)
+    }
     load_tables_256(&tab);
     __syncthreads();
+    if (ZC && id >= nblkB + nsrc_wg) {
+        const int k = id - (nblkB + nsrc_wg);           // cell workgroups: (chunk, tile of TW walkers)
+        const int ntc = (B + TW - 1) / TW;
+        const int cc = k / ntc, w0c = (k - cc * ntc) * TW;
+        zcell_body<TW>(kc, zc, wrec, cc, w0c, min(TW, B - w0c), tab, red);
+        return;
+    }
     if (id < nblkB) {
         if (CMP && VARIANT == LF_FREE && gc.nb > 0) gridc_body<TWB>(kc, gc, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red, Tw);
         else gridsum_body<VARIANT, TWB>(kc, na, wrec, wmode, B, ntilesB, twb, id, partB, strideB, tab, red);

@@ -111,6 +111,7 @@ struct lf_ctx {
     bool any_enqueued = false;
     // profiling
     int profiling = 0;   // 0 off, 1 lf_main only, 2 every launch
+    lf::ZCells zcells{};                // ZEVOL, real catalogue: the cell workgroups' arguments for the launch being enqueued (nchC = 0: none)
     int64_t opt_profile_every = 1;      // ... of every n-th evaluation only (an event pair costs the stream ~4 us: it drains the queue)
     int64_t prof_tick = 0;
     bool prof_this = true;              // (this evaluation is one of them)
@@ -143,22 +144,59 @@ int upload(lf_ctx* c, T** dst, const T* src, size_t n) {
 // box are -inf before any sum is looked at).  x = the flux-sorted logf.  Walker-independent: built once.  A field with a
 // non-finite flux, or a prior box so wide in alpha_C that cells would hold fewer than four sources on average, gets
 // none (kc.cells = 0: every walker is summed over the sources, as before).
-int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf) {
+// ZEVOL: half the width of a cell in redshift such that every walker inside the prior box of (L1, L2, L3) may be summed
+// over the cells (lf_kernels.h: ZCELL_X1, ZCELL_X2).  L*(z) is the parabola through (pivot_i, L_i): its slope at a given
+// z and its curvature are linear in (L1, L2, L3), so their largest magnitudes over the box are taken at its corners, and
+// the slope's over the catalogue's redshifts at their ends.  0: no cells (an unbounded box, coinciding pivots).
+double zcell_rho_for_box(const lf::KConst& kc, int nf) {
+    using namespace lf;
+    const double lo = kc.lims[LF_LIM_LSTAR][0], hi = kc.lims[LF_LIM_LSTAR][1];
+    double zmin = HUGE_VAL, zmax = -HUGE_VAL;
+    for (int f = 0; f < nf; ++f)
+        if (kc.nsrc[f] > 0) {
+            zmin = std::fmin(zmin, kc.z_lo[f]);
+            zmax = std::fmax(zmax, kc.z_hi[f]);
+        }
+    if (!(std::isfinite(lo) && std::isfinite(hi) && std::isfinite(zmin) && std::isfinite(zmax))) return 0.0;
+    const double z1 = kc.pivots[0], z2 = kc.pivots[1], z3 = kc.pivots[2];
+    if (!(z1 != z2 && z2 != z3 && z1 != z3)) return 0.0;
+    double smax = 0.0, amax = 0.0;
+    for (int corner = 0; corner < 8; ++corner) {
+        const double L1 = corner & 1 ? hi : lo, L2 = corner & 2 ? hi : lo, L3 = corner & 4 ? hi : lo;
+        const double d12 = (L2 - L1) / (z2 - z1), d23 = (L3 - L2) / (z3 - z2);
+        const double a = (d23 - d12) / (z3 - z1);                     // divided differences: L* = L1 + d12 (z - z1) + a (z - z1)(z - z2)
+        for (double z : {zmin, zmax}) smax = std::fmax(smax, std::fabs(d12 + a * (2.0 * z - z1 - z2)));
+        amax = std::fmax(amax, std::fabs(a));
+    }
+    double rho = ZCELL_RHO;
+    // (a little inside the limits: lf_prepare evaluates the same quantities from its own rounded coefficients)
+    if (smax > 0.0) rho = std::fmin(rho, 0.98 * ZCELL_X1 / (LF_LN10 * smax));
+    if (amax > 0.0) rho = std::fmin(rho, std::sqrt(0.98 * ZCELL_X2 / (LF_LN10 * amax)));
+    return std::isfinite(rho) ? rho : 0.0;
+}
+
+// wts: NULL (FREE: cells in log-flux, plain power sums, chunks of 64 cells) or the sources' weights (ZEVOL: cells in
+// redshift, S_j = sum_i wts_i d_i^j, chunks of BLOCK cells; lf_kernels.h: ZCELL_RHO)
+int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf, const double* wts = nullptr) {
     using namespace lf;
     const double ahi = kc.lims[LF_LIM_ALPHA][1];
-    if (!(ahi > 0.0) || !std::isfinite(ahi)) return LF_OK;
-    const double rho = std::fmin(CELL_RHO_H, CELL_RHO_G / ahi);
+    if (!wts && (!(ahi > 0.0) || !std::isfinite(ahi))) return LF_OK;
+    const double rho = wts ? kc.zcell_rho : std::fmin(CELL_RHO_H, CELL_RHO_G / ahi);
+    if (!(rho > 0.0)) return LF_OK;
+    const size_t per_chunk = wts ? (size_t)BLOCK : 64;
     std::vector<double> cd;
     std::vector<int> cst, cln, cfl;
     for (int f = 0; f < nf; ++f) {
         const int64_t lo = c->field_ind[f], hi = c->field_ind[f + 1];
         if (hi <= lo) continue;
         for (int64_t i = lo; i < hi; ++i)
-            if (!std::isfinite(x[(size_t)i])) return LF_OK;
-        const double k0 = std::floor((x[(size_t)lo] - kc.key_x0) * KEY_SCALE), k1 = std::ceil((x[(size_t)hi - 1] - kc.key_x0) * KEY_SCALE);
-        if (!(k0 >= 0.0 && k1 < (double)KEY_MAX)) return LF_OK;
-        kc.kf_first[f] = (int)k0;
-        kc.kf_last[f] = (int)k1;
+            if (!std::isfinite(x[(size_t)i]) || (wts && !(std::isfinite(wts[(size_t)i]) && wts[(size_t)i] > 0.0))) return LF_OK;
+        if (!wts) {
+            const double k0 = std::floor((x[(size_t)lo] - kc.key_x0) * KEY_SCALE), k1 = std::ceil((x[(size_t)hi - 1] - kc.key_x0) * KEY_SCALE);
+            if (!(k0 >= 0.0 && k1 < (double)KEY_MAX)) return LF_OK;
+            kc.kf_first[f] = (int)k0;
+            kc.kf_last[f] = (int)k1;
+        }
         const size_t first_cell = cd.size() / 8;
         for (int64_t i = lo; i < hi;) {
             int64_t j = i + 1;
@@ -167,7 +205,7 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf)
             long double S[CELL_M + 1] = {0};
             for (int64_t k = i; k < j; ++k) {
                 const long double dlt = (long double)x[(size_t)k] - (long double)xc;
-                long double pw = 1.0L;
+                long double pw = wts ? (long double)wts[(size_t)k] : 1.0L;
                 for (int m = 0; m <= CELL_M; ++m) {
                     S[m] += pw;
                     pw *= dlt;
@@ -178,9 +216,9 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf)
             i = j;
         }
         const size_t ncf = cd.size() / 8 - first_cell;
-        for (size_t s0 = 0; s0 < ncf; s0 += 64) {                       // a cell chunk = one wave's lanes (lf_free.h)
+        for (size_t s0 = 0; s0 < ncf; s0 += per_chunk) {                // a cell chunk = one wave's lanes (lf_free.h) / one workgroup's threads
             cst.push_back((int)(first_cell + s0));
-            cln.push_back((int)std::min<size_t>(64, ncf - s0));
+            cln.push_back((int)std::min<size_t>(per_chunk, ncf - s0));
             cfl.push_back(f);
         }
     }
@@ -422,8 +460,14 @@ void launch_geo(lf_ctx* c, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int n
         std::fprintf(stderr, "lf_main<%d,%d,%d,%d,%d>: %d workgroups per CU (occupancy API), %d VGPRs, %zu B LDS, grid %u\n", VARIANT,
                      GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, (int)CMP, nb, fa.numRegs, fa.sharedSizeBytes, grid.x);
     }
+    ZCells zc{};
+    if (VARIANT == LF_ZEVOL && !CMP && c->zcells.nchC > 0) {
+        zc = c->zcells;                           // cell workgroups after the per-source ones: (chunk, tile of TW walkers)
+        grid.x += (unsigned)(zc.nchC * ((B + GEOS[GI].tw - 1) / GEOS[GI].tw));
+        c->last_launch[4] = (int)grid.x;
+    }
     hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, CMP>), grid, dim3(BLOCK), 0, s, c->kc, sa,
-                       na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB, rs, gc);
+                       na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB, rs, gc, zc);
 }
 
 // compressed-catalogue launches: the pseudo-sources are few, so only the small-tile geometries are instantiated
@@ -614,8 +658,11 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     const int nresc = cmp ? std::min(nchD, std::min(1024, std::max(128, 2 * B))) : 0;
     const bool cgrid = cmp && c->gridc.built && c->opt_compress_grid && !c->opt_skip_grid;
     const int nchB = c->opt_skip_grid ? 0 : (cgrid ? (c->gridc.nb + 15) / 16 : (c->nnodes + BLOCK - 1) / BLOCK);
-    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * nchD);
+    // ZEVOL on the real catalogue: walkers lf_prepare flags STAT_CELLS are summed over the cells in redshift (partR)
+    const int nchC = !cmp && c->kc.variant == LF_ZEVOL && c->kc.cells ? c->ncchunk : 0;
+    rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * std::max(nchD, nchC));
     if (rc != LF_OK) return rc;
+    c->zcells = ZCells{c->d_cells, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat};
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
@@ -700,8 +747,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     {
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
-                           cmp ? c->d_partR : nullptr, nchD, (int)STAT_SLOW, c->d_wstat, c->d_wbase, B, ap, d_out, d_outA, d_outB,
-                           cmp ? c->d_slow : nullptr);
+                           cmp || nchC > 0 ? c->d_partR : nullptr, cmp ? nchD : nchC, (int)(cmp ? STAT_SLOW : STAT_CELLS), c->d_wstat,
+                           c->d_wbase, B, ap, d_out, d_outA, d_outB, cmp ? c->d_slow : nullptr);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;
@@ -1077,11 +1124,18 @@ int build(lf_ctx* c, const lf_desc* d) {
     }
     int rc;
     kc.cells = 0;
+    kc.zcell_rho = 0.0;
     for (int f = 0; f < MAXF; ++f) {
         kc.kf_first[f] = 0;
         kc.kf_last[f] = lf::KEY_MAX;
     }
     if (d->variant == LF_FREE && (rc = build_cells(c, kc, a1, nf)) != LF_OK) return rc;
+    if (d->variant == LF_ZEVOL) {
+        std::vector<double> wts((size_t)N);
+        for (int64_t i = 0; i < N; ++i) wts[(size_t)i] = std::pow(10.0, lumv[(size_t)i] - LF_LREF);
+        kc.zcell_rho = zcell_rho_for_box(kc, nf);
+        if ((rc = build_cells(c, kc, a1, nf, wts.data())) != LF_OK) return rc;
+    }
     if ((rc = upload(c, &c->d_lum, lumv.data(), (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a1, a1.data(), (size_t)N)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_P, P.data(), (size_t)N)) != LF_OK) return rc;

@@ -350,6 +350,7 @@ def test_zevol_local_form_equals_the_per_source_form(n, nf, zslices, pivots):
     th[8:, 0:3] = rng.uniform(41.2, 44.8, (32, 3))
     ref = O.lnprob_batch(inp, th[:10])
     ctx = LFContext(inp)
+    ctx.set_option("cells", 0)                               # (per source: the cells in redshift have their own test below)
     a1, b1 = ctx.lnprob_pieces(th)
     lp1 = ctx.lnprob_batch(th)
     ctx.set_option("specialise", 0)
@@ -364,3 +365,43 @@ def test_zevol_local_form_equals_the_per_source_form(n, nf, zslices, pivots):
     np.testing.assert_allclose(lp1[:10][f10], ref[f10], rtol=RTOL)
     if n == 400000:
         assert not np.array_equal(a1[fin], a0[fin])          # (the local form did run: only FAST-mode walkers take it)
+
+
+@pytest.mark.parametrize("n,nf,zslices,pivots,rows", [(400000, 5, 8, (1.20, 1.53, 1.86), 40), (250001, 3, 0, (1.18, 1.36, 1.54), 40),
+                                                      (33333, 4, 0, (1.20, 1.76, 2.32), 21), (1000000, 5, 0, None, 128)])
+def test_zevol_cells_equal_the_sum_over_sources(n, nf, zslices, pivots, rows):
+    """The z-evolving variant summed over the catalogue's cells in REDSHIFT (lf_kernels.h: ZCELL_RHO, zcell_body) against
+    the sum over the sources ("cells" = 0) and against the oracle.  Walkers over the whole prior box of L1..L3 (steep and
+    curved L*(z): the cells' width was chosen for the box, so every walker inside it takes them) and beyond it (-inf
+    without being evaluated), ragged chunks, redshift slices with gaps between them."""
+    from lumfuncmcmc_amd.capi import LFContext
+    kw = {} if pivots is None else {"pivots": pivots}
+    inp = make_inputs("zevol", n, seed=41, nf=nf, zslices=zslices, **kw)
+    th = synth.walkers("zevol", rows, seed=42, nf=nf)
+    rng = np.random.default_rng(43)
+    wild = np.arange(rows) % 4 == 3                         # every 4th walker anywhere in the box
+    th[wild, 0:3] = rng.uniform(41.2, 44.8, (int(wild.sum()), 3))
+    ref = O.lnprob_batch(inp, th[:6]) if n <= 400000 else None
+    ctx = LFContext(inp)
+    ctx.set_option("count_forms", 1)
+    a1, b1 = ctx.lnprob_pieces(th)
+    ncell = ctx.form_counts()["cell"]
+    ctx.set_option("count_forms", 0)
+    lp1 = ctx.lnprob_batch(th)
+    ctx.set_option("cells", 0)
+    a0, b0 = ctx.lnprob_pieces(th)
+    lp0 = ctx.lnprob_batch(th)
+    ctx.close()
+    assert ncell > 0                                         # the cell workgroups ran
+    assert np.array_equal(np.isinf(lp1), np.isinf(lp0)) and not np.isnan(lp1).any()
+    fin = np.isfinite(lp0)
+    assert fin.sum() >= rows // 2
+    # piece A is (closed form) - sum_i v_i: the difference of the two sums of v against the sum itself (the closed form
+    # is common to both and can be much larger or smaller than the sum)
+    np.testing.assert_allclose(a1[fin], a0[fin], rtol=1e-13)
+    np.testing.assert_array_equal(b1[fin], b0[fin])
+    np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=1e-13)
+    assert not np.array_equal(a1[~wild & fin], a0[~wild & fin])          # (the gentle walkers did take the cells)
+    if ref is not None:
+        f6 = np.isfinite(ref)
+        np.testing.assert_allclose(lp1[:6][f6], ref[f6], rtol=RTOL)
