@@ -244,6 +244,8 @@ class Leg(object):
             ctx.set_option("specialise", 0)
         if args.no_tables:
             ctx.set_option("tables", 0)
+        if args.no_cells:
+            ctx.set_option("cells", 0)
         self.ndim = ctx.ndim
         # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
         self.theta_all = synth.walkers(args.variant, self.half * nblk, seed=seed).reshape(nblk, self.half, self.ndim)
@@ -420,6 +422,7 @@ def main():
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
     ap.add_argument("--no-extras", action="store_true", help="only the timed loop: no device-sampler / compressed-catalogue / strong-scaling legs (profiling runs)")
     ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
+    ap.add_argument("--no-cells", action="store_true", help="A/B: every walker summed over the sources, not over the catalogue's cells")
     ap.add_argument("--no-tables", action="store_true", help="A/B: the general form of the free term only (no g/h tables)")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
@@ -522,6 +525,9 @@ def main():
                           "walkers_total": Wtot, "variant": args.variant, "shard": shard if world > 1 else "none",
                           "parallelism": par},
                "roofline": roofline_of(args, leg, model, kt, dt)}
+    ab = [n for n in ("no_cells", "no_tables", "no_specialise", "compress", "taper") if getattr(args, n)]
+    if ab and rank == 0:
+        res["config"]["ab_options"] = ab                    # an A/B run, not the default path
     if world > 1 and scaling == "weak" and not args.no_extras:
         # the metric's literal shape - a FIXED ensemble of --walkers walkers - on the same GPUs, in the same run:
         # sharded by walker (all-gather) and by source (all-reduce)

@@ -52,7 +52,9 @@ struct FreeArgs {
     double* partA;            // [B][nchA]
     double* partB;            // [B][nslot]: the grid integral, one partial per (walker, workgroup of its tile)
     // cells (lf_kernels.h: CELL_M): walkers flagged STAT_CELLS by lf_prepare are summed over them instead of the sources
-    const double* cells;      // [ncell][8] {x_c, S_0 .. S_6}
+    const double* cells;      // [nchC * 64][8] {x_c, S_0 .. S_6}: every field's cells padded to whole chunks of 64 (pads: all sums 0)
+    const double* nodes8;     // [nchB * 64][8] {G, PG, W, a3, a4, the chunk's smallest a4, -, -}: the grid's nodes, one 64-byte
+                              // record per node, padded to whole chunks (pads: W = 0)
     const int* cc_start;      // [nchC] first cell of a cell chunk
     const int* cc_len;        // [nchC] its cells (<= 64: one per lane of a wave; the waves take one walker each)
     const int* cc_field;      // [nchC]
@@ -207,16 +209,25 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             // (the chunks are dealt statically, so the order of the sums is fixed by the launch geometry).
             double acc = 0.0;
             if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && frank < fa.nchC) {       // (wave-uniform)
+                // (Nothing but these loads goes through the vector memory counter inside the loop - chunk cc starts at cell
+                // 64 cc, its field comes from KConst by scalar compares, pads need no masking - so the next chunk's cells
+                // really are in flight while the current chunk is summed.  With the chunk table read from memory and the
+                // lanes past the end masked, every chunk waited for its own loads twice over.)
                 auto load_cells = [&](double (&d)[8], int cc) {
                     const int lane = fresh_tid() & 63;      // (made here: carried through the loop it is spilled in one instantiation)
-                    const int c0 = uni(fa.cc_start[cc]), ncl = uni(fa.cc_len[cc]);
-                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.cells + (size_t)(c0 + min(lane, ncl - 1)) * 8);
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.cells + ((size_t)cc * 64 + lane) * 8);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const double2 a = src[k];
-                        d[2 * k] = lane < ncl || k == 0 ? a.x : 0.0;     // (x_c always; a lane past the end: every power sum 0)
-                        d[2 * k + 1] = lane < ncl ? a.y : 0.0;
+                        d[2 * k] = a.x;
+                        d[2 * k + 1] = a.y;
                     }
+                };
+                auto field_of = [&](int cc) {               // (scalar: cc and the table are wave-uniform)
+                    int f = 0;
+#pragma unroll
+                    for (int k = 1; k < MAXF; ++k) f += cc >= kc.cc_fstart[k] ? 1 : 0;
+                    return f;
                 };
                 double nx[8];
                 load_cells(nx, frank);
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #pragma unroll
                     for (int k = 0; k < 8; ++k) cd[k] = nx[k];
                     if (cc + fgroup < fa.nchC) load_cells(nx, cc + fgroup);
-                    const WalkerK p = fetch(v, uni(fa.cc_field[cc]));
+                    const WalkerK p = fetch(v, field_of(cc));
                     asm volatile("; LF_BEGIN cell items=1");
                     acc += cell_sum(cd, p, &tt);
                     asm volatile("; LF_END cell");
@@ -262,12 +273,13 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 // (source-sharded ranks split the grid: this context integrates the chunks c with c % parts == part)
                 auto mine = [&](int c) { return mode != MODE_SKIP && !(kc.grid_parts > 1 && c % kc.grid_parts != kc.grid_part); };
                 struct Node {
-                    double G, PG, W, a3, a4;
+                    double G, PG, W, a3, a4, a4min;
                 };
-                auto load_nodes = [&](int c) -> Node {
+                auto load_nodes = [&](int c) -> Node {      // (one 64-byte record per lane; see load_cells)
                     const int lane = fresh_tid() & 63;
-                    const int g = min(c * 64 + lane, na.nnodes - 1);
-                    return Node{na.G[g], na.PG[g], c * 64 + lane < na.nnodes ? na.W[g] : 0.0, na.a3[g], na.a4[g]};
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.nodes8 + ((size_t)c * 64 + lane) * 8);
+                    const double2 a = src[0], b = src[1], d = src[2];
+                    return Node{a.x, a.y, b.x, b.y, d.x, d.y};
                 };
                 Node nx = load_nodes(frank);      // the next chunk's nodes are in flight while the current one is summed
 #pragma unroll 1
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     const Node nd = nx;
                     if (c + fgroup < nch64) nx = load_nodes(c + fgroup);
                     if (mine(c)) {
-                        const double a4min = uni(na.a4min64[c]);       // the chunk's faintest node, for the bright form of the field sum
+                        const double a4min = uni(nd.a4min);            // the chunk's faintest node, for the bright form of the field sum
                         const double T = fexp_c(fma(uni(sc[R_C1]), nd.G - uni(sc[R_LSTAR]), uni(sc[R_C0])) - nd.PG * uni(sc[R_Q]), &tab);
                         const bool bright = kc.specialise && alphaC > 0.0 && a4min * vmin > 37.5;
                         if (CENSUS && kc.forms && (fresh_tid() & 63) == 0)

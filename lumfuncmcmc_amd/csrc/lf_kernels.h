@@ -83,6 +83,7 @@ struct KConst {
     int variant, fix_sch_al, nf, S, ndim;
     int specialise;           // 1: chunk-level term specialisation (term_free_noexp); 0 for A/B runs
     int cells;                // FREE, ZEVOL: 1 = the catalogue's cells exist and lf_prepare may flag walkers STAT_CELLS
+    int cc_fstart[MAXF + 1];  // FREE: cell chunks (64 cells) of field f are [cc_fstart[f], cc_fstart[f + 1])
     double zcell_rho;         // ZEVOL: half the largest width of a cell in redshift (ZCELL_RHO below)
     int kf_first[MAXF], kf_last[MAXF];   // FREE: keys (floor / ceil) of each field's faintest / brightest source
     int grid_part, grid_parts; // source-sharded ranks split piece B too: this context integrates the node chunks c with
@@ -973,7 +974,6 @@ struct NodeArrays {
     const double* a3;     // FREE: logf on the grid                ZEVOL: zarr[k]
     const double* a4;     // FREE: 10^(logf_grid + 17)             ZEVOL: zarr[k]^2
     const double* a4min;  // FREE: per chunk of 256 nodes, the smallest a4 (for the bright form, field_sum_bright)
-    const double* a4min64;   // ... per chunk of 64 nodes (lf_free)
     int nnodes;
 };
 

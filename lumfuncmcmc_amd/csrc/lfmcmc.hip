@@ -72,7 +72,7 @@ struct lf_ctx {
     int num_cu = 0;
     // device tables
     double *d_lum = nullptr, *d_a1 = nullptr, *d_P = nullptr, *d_U = nullptr;
-    double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr, *d_a4min = nullptr, *d_a4min64 = nullptr;
+    double *d_G = nullptr, *d_PG = nullptr, *d_W = nullptr, *d_a3 = nullptr, *d_a4 = nullptr, *d_a4min = nullptr, *d_nodes8 = nullptr;
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     std::map<int, ChunkTable> chunks_free;   // the persistent FREE kernel's (lf_free.h): 512 ST sources per chunk, lanes of ST
     int64_t opt_persistent = 1;         // FREE: 1 = lf_free (persistent 512-thread workgroups) for catalogues that fill it
@@ -186,6 +186,7 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
     const size_t per_chunk = wts ? (size_t)BLOCK : 64;
     std::vector<double> cd;
     std::vector<int> cst, cln, cfl;
+    size_t nreal = 0;                    // cells with sources
     for (int f = 0; f < nf; ++f) {
         const int64_t lo = c->field_ind[f], hi = c->field_ind[f + 1];
         if (hi <= lo) continue;
@@ -215,15 +216,32 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
             for (int m = 0; m <= CELL_M; ++m) cd.push_back((double)S[m]);
             i = j;
         }
-        const size_t ncf = cd.size() / 8 - first_cell;
+        size_t ncf = cd.size() / 8 - first_cell;
+        nreal += ncf;
+        if (!wts) {
+            // lf_free addresses chunk cc at cell 64 cc and masks nothing: pad the field to whole chunks with cells of no
+            // sources (all sums 0) at the last real midpoint (inside the tables wherever the real cell is)
+            kc.cc_fstart[f] = (int)cst.size();
+            const double xlast = cd[cd.size() - 8];
+            while (ncf % 64) {
+                cd.push_back(xlast);
+                for (int m = 0; m <= CELL_M; ++m) cd.push_back(0.0);
+                ++ncf;
+            }
+        }
         for (size_t s0 = 0; s0 < ncf; s0 += per_chunk) {                // a cell chunk = one wave's lanes (lf_free.h) / one workgroup's threads
             cst.push_back((int)(first_cell + s0));
-            cln.push_back((int)std::min<size_t>(per_chunk, ncf - s0));
+            cln.push_back((int)std::min<size_t>(per_chunk, ncf - s0));        // (FREE: pads included; they add 0)
             cfl.push_back(f);
         }
     }
     const size_t ncell = cd.size() / 8;
-    if (ncell == 0 || (size_t)c->N < 4 * ncell) return LF_OK;         // (too few sources per cell to pay)
+    if (!wts) {                                                       // (a field without cells starts where the next one does)
+        for (int f = nf; f <= MAXF; ++f) kc.cc_fstart[f] = (int)cst.size();
+        for (int f = nf - 1; f >= 0; --f)
+            if (c->field_ind[f + 1] <= c->field_ind[f]) kc.cc_fstart[f] = kc.cc_fstart[f + 1];
+    }
+    if (nreal == 0 || (size_t)c->N < 4 * nreal) return LF_OK;         // (too few sources per cell to pay)
     int rc;
     if ((rc = upload(c, &c->d_cells, cd.data(), cd.size())) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_cc_start, cst.data(), cst.size())) != LF_OK) return rc;
@@ -587,9 +605,9 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
                            c->d_wstat, c->d_wmode, c->d_wbase, (int*)nullptr, c->d_queue, ntiles * QSTRIDE);
     }
     const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
-    const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_a4min64, c->nnodes};
+    const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
     FreeArgs fa{B, ntiles, nchA, nchB, nslot, g8, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
-                c->d_cells, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat};
+                c->d_cells, c->d_nodes8, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat};
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
@@ -695,7 +713,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         rs.nchD = nchD;
         rs.nresc = nresc;
     }
-    NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_a4min64, c->nnodes};
+    NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
     {
         Prof p(c, s, 1);
         int tw = geo.tw, twb = geo.twb;
@@ -969,7 +987,7 @@ void free_ctx(lf_ctx* c) {
         for (int* b : gi_)
             if (b) hipFree(b);
     }
-    double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_a4min64,
+    double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_nodes8,
                       c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
     for (double* b : bufs)
         if (b) hipFree(b);
@@ -1129,6 +1147,7 @@ int build(lf_ctx* c, const lf_desc* d) {
         kc.kf_first[f] = 0;
         kc.kf_last[f] = lf::KEY_MAX;
     }
+    for (int f = 0; f <= MAXF; ++f) kc.cc_fstart[f] = 0;
     if (d->variant == LF_FREE && (rc = build_cells(c, kc, a1, nf)) != LF_OK) return rc;
     if (d->variant == LF_ZEVOL) {
         std::vector<double> wts((size_t)N);
@@ -1213,14 +1232,27 @@ int build(lf_ctx* c, const lf_desc* d) {
             a4min[ch] = d->variant == LF_FREE ? m : 0.0;
         }
         if ((rc = upload(c, &c->d_a4min, a4min.data(), a4min.size())) != LF_OK) return rc;
-        // ... and per chunk of 64 nodes (lf_free: a wave's lanes)
-        std::vector<double> a4min64((nn + 63) / 64, 0.0);
-        for (size_t ch = 0; ch < a4min64.size(); ++ch) {
-            double m = HUGE_VAL;
-            for (size_t g = ch * 64; g < std::min(nn, (ch + 1) * 64); ++g) m = std::isnan(a4[g]) ? 0.0 : std::fmin(m, a4[g]);
-            a4min64[ch] = d->variant == LF_FREE ? m : 0.0;
+        // lf_free reads the nodes as 64-byte records {G, PG, W, a3, a4, smallest a4 of the node's chunk of 64, -, -}, padded
+        // to whole chunks (pads: the last node again with W = 0): one contiguous load per lane, nothing to mask
+        if (d->variant == LF_FREE) {
+            const size_t nch64 = (nn + 63) / 64;
+            std::vector<double> n8(nch64 * 64 * 8, 0.0);
+            for (size_t ch = 0; ch < nch64; ++ch) {
+                double m = HUGE_VAL;
+                for (size_t g = ch * 64; g < std::min(nn, (ch + 1) * 64); ++g) m = std::isnan(a4[g]) ? 0.0 : std::fmin(m, a4[g]);
+                for (size_t l = 0; l < 64; ++l) {
+                    const size_t g = std::min(ch * 64 + l, nn - 1);
+                    double* r = &n8[(ch * 64 + l) * 8];
+                    r[0] = G[g];
+                    r[1] = PG[g];
+                    r[2] = ch * 64 + l < nn ? W[g] : 0.0;
+                    r[3] = a3[g];
+                    r[4] = a4[g];
+                    r[5] = m;
+                }
+            }
+            if ((rc = upload(c, &c->d_nodes8, n8.data(), n8.size())) != LF_OK) return rc;
         }
-        if ((rc = upload(c, &c->d_a4min64, a4min64.data(), a4min64.size())) != LF_OK) return rc;
     }
     {
         hipDeviceProp_t prop;

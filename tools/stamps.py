@@ -70,6 +70,12 @@ def main():
     print("                    walker loops (passes 1 and 2)                            ", pm(s[:, 7]))
     print("                    barrier C + reduction + stores                           ", pm(t_red))
     print("   the rest (node chunks, tile set-up, end)                                  ", pm(life - s[:, 3] - s[:, 4] - s[:, 7] - t_red))
+    # who is slow?  by XCD (workgroup index mod 8 under round-robin placement) and by the group of 8 the workgroup is in
+    ids = np.nonzero(out[:, 0] > 0)[0]
+    for name, key in (("XCD", ids & 7), ("group of 8", ids >> 3)):
+        ks = sorted(set(key.tolist()))[:64]
+        print("median life by %s: %s" % (name, " ".join("%d:%.0f" % (k, np.median(life[key == k])) for k in ks)))
+        print("median END (us after the first start) by %s: %s" % (name, " ".join("%d:%.1f" % (k, np.median(s[key == k, 6] - s[:, 5].min()) / 100.0) for k in ks)))
     print("start spread %.1f us; first start to last end %.1f us" % ((s[:, 5].max() - s[:, 5].min()) / 100.0, (s[:, 6].max() - s[:, 5].min()) / 100.0))
     rt = s[:, 6]
     print("spread of the workgroups' end times: %.1f us" % ((rt.max() - rt.min()) / 100.0))
