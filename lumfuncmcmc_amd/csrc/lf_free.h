@@ -52,7 +52,7 @@ struct FreeArgs {
     double* partA;            // [B][nchA]
     double* partB;            // [B][nslot]: the grid integral, one partial per (walker, workgroup of its tile)
     // cells (lf_kernels.h: CELL_M): walkers flagged STAT_CELLS by lf_prepare are summed over them instead of the sources
-    const double* cells;      // [nchC * 64][8] {x_c, S_0 .. S_6}: every field's cells padded to whole chunks of 64 (pads: all sums 0)
+    const double* cells;      // [nchC * 64][CELL_REC] {x_c, S_0 .. S_8}: every field's cells padded to whole chunks of 64 (pads: all sums 0)
     const double* nodes8;     // [nchB * 64][8] {G, PG, W, a3, a4, the chunk's smallest a4, -, -}: the grid's nodes, one 64-byte
                               // record per node, padded to whole chunks (pads: W = 0)
     const int* cc_start;      // [nchC] first cell of a cell chunk
@@ -213,11 +213,12 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 // 64 cc, its field comes from KConst by scalar compares, pads need no masking - so the next chunk's cells
                 // really are in flight while the current chunk is summed.  With the chunk table read from memory and the
                 // lanes past the end masked, every chunk waited for its own loads twice over.)
-                auto load_cells = [&](double (&d)[8], int cc) {
+                auto load_cells = [&](double (&d)[CELL_REC], int cc) {
                     const int lane = fresh_tid() & 63;      // (made here: carried through the loop it is spilled in one instantiation)
-                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.cells + ((size_t)cc * 64 + lane) * 8);
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(fa.cells + ((size_t)cc * 64 + lane) * CELL_REC);
+                    static_assert(CELL_REC % 2 == 0, "16-byte loads");
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < CELL_REC / 2; ++k) {
                         const double2 a = src[k];
                         d[2 * k] = a.x;
                         d[2 * k + 1] = a.y;
@@ -229,13 +230,13 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     for (int k = 1; k < MAXF; ++k) f += cc >= kc.cc_fstart[k] ? 1 : 0;
                     return f;
                 };
-                double nx[8];
+                double nx[CELL_REC];
                 load_cells(nx, frank);
 #pragma unroll 1
                 for (int cc = frank; cc < fa.nchC; cc += fgroup) {
-                    double cd[8];
+                    double cd[CELL_REC];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) cd[k] = nx[k];
+                    for (int k = 0; k < CELL_REC; ++k) cd[k] = nx[k];
                     if (cc + fgroup < fa.nchC) load_cells(nx, cc + fgroup);
                     const WalkerK p = fetch(v, field_of(cc));
                     asm volatile("; LF_BEGIN cell items=1");

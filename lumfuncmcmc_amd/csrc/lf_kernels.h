@@ -42,13 +42,16 @@ enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2, MODE_SKIP = 3, MODE_SKIPSR
 enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4,      // SLOW: some field of the walker takes the careful path
        STAT_CELLS = 8 };   // FREE: piece A of this walker is summed over the catalogue's CELLS (lf_free.h), not its sources
 // Cells (FREE, real catalogue): a cell is a run of flux-neighbouring sources of one field no wider than 2 rho, stored as
-// {x_c, S_0 .. S_6}: its midpoint and the power sums S_j = sum_k (x_k - x_c)^j.  On a table piece the term is the
+// {x_c, S_0 .. S_8}: its midpoint and the power sums S_j = sum_k (x_k - x_c)^j.  On a table piece the term is the
 // product of two degree-7 polynomials, g(t_c + sa d) h(u_c + d) = sum_j c_j d^j, so the cell's sum over its sources
 // is sum_j c_j S_j - whatever the number of sources.  Orders above CELL_M are dropped: with alpha_C rho <= CELL_RHO_G
-// and rho <= CELL_RHO_H their share of any term is below 3e-17 for every piece of both tables
-// (tests/test_tables_cpu.py recomputes that bound from the tables' coefficients).
-constexpr int CELL_M = 6;
-constexpr double CELL_RHO_G = 5.0e-3, CELL_RHO_H = 1.0e-3;
+// and rho <= CELL_RHO_H their share of any term is below 2e-18 for every piece of both tables
+// (tests/test_tables_cpu.py recomputes that bound from the tables' coefficients).  Both radii stay inside the tables'
+// margins (a cell lies within the margins of its midpoint's pieces).  (With CELL_M = 6 the same bound needed cells a
+// third as wide: three times the cells at 0.82 of the cost each.)
+constexpr int CELL_M = 8;
+constexpr int CELL_REC = CELL_M + 2;         // doubles per cell record
+constexpr double CELL_RHO_G = 1.5e-2, CELL_RHO_H = 3.0e-3;
 // ZEVOL has cells too, in REDSHIFT.  What is left of the term per source is v_i = 10^(lum_i - L*(z_i)) with L* a
 // quadratic aL z^2 + bL z + cL of the walker (lumfuncmcmc_z.py:66): about a cell's midpoint z_c, with d = z_i - z_c,
 //     v_i = 10^(lum_i - LREF) * 10^(LREF - L*(z_c)) * exp(a d + b d^2),   a = -ln10 L*'(z_c),  b = -ln10 aL
@@ -57,9 +60,11 @@ constexpr double CELL_RHO_G = 5.0e-3, CELL_RHO_H = 1.0e-3;
 // weights positive, so a relative error of the series is a relative error of the cell's sum.  Cells are at most
 // 2 rho wide, and a walker takes them when |a| rho <= ZCELL_X1 over the field's redshifts and |b| rho^2 <= ZCELL_X2
 // (lf_prepare): the orders above CELL_M then sum to less than 1e-17 (tests/test_tables_cpu.py recomputes the bound from
-// the majorant series exp(X1 t + X2 t^2)).  rho (KConst::zcell_rho) is chosen when the context is made, at most
+// the majorant series exp(X1 t + X2 t^2)).  Records {z_c, S_0 .. S_6}: ZCELL_M = 6.  rho (KConst::zcell_rho) is chosen when the context is made, at most
 // ZCELL_RHO and small enough that EVERY walker inside the prior box of L1..L3 passes (lfmcmc.hip: zcell_rho_for_box).
 constexpr double ZCELL_RHO = 1.0e-3, ZCELL_X1 = 6.0e-3, ZCELL_X2 = 1.0e-5;
+constexpr int ZCELL_M = 6;
+constexpr int ZCELL_REC = ZCELL_M + 2;
 
 // walker record, FREE / FIXCOMP: walker scalars ...
 enum { R_LSTAR = 0, R_C0 = 1, R_C1 = 2, R_Q = 3, R_ALPHAC = 4 };
@@ -928,16 +933,18 @@ __device__ __forceinline__ double table_terms(const TabCoef& C, const double (&x
 }
 
 // One cell for one walker: sum over the cell's sources of g(num) h(y) = sum_j c_j S_j (see CELL_M above).  cd = {x_c,
-// S_0 .. S_6}.  Per (walker, cell): the piece lookup at x_c, the Taylor shifts of both piece polynomials to the cell's
-// midpoint (28 FMAs each for orders 0 .. 6 of a degree-7 polynomial), the powers of the slope, the product series and
-// the dot product with the power sums: ~125 fp64 instructions whatever the number of sources in the cell.
-__device__ __forceinline__ double cell_sum(const double (&cd)[8], const WalkerK& p, const TermTables* __restrict__ tt) {
+// S_0 .. S_8}.  Per (walker, cell): the piece lookup at x_c, the Taylor shifts of both piece polynomials to the cell's
+// midpoint (28 FMAs each), the powers of the slope, the product series up to order CELL_M (the polynomials have no
+// order above 7) and the dot product with the power sums: ~150 fp64 instructions whatever the number of sources in
+// the cell.
+__device__ __forceinline__ double cell_sum(const double (&cd)[CELL_REC], const WalkerK& p, const TermTables* __restrict__ tt) {
+    static_assert(CELL_M >= 7 && CELL_M <= 14, "the product of two degree-7 polynomials");
     TabCoef C;
     const double xs[1] = {cd[0]};
     table_lookup<1>(C, xs, p, false, tt);          // (bright cells land on the h table's last piece, the constant 1)
     const double tc = fma(C.sa, cd[0], C.sc), uc = cd[0] + C.dy;
 #pragma unroll
-    for (int j = 0; j <= CELL_M; ++j) {
+    for (int j = 0; j <= 6; ++j) {
 #pragma unroll
         for (int i = 6; i >= j; --i) {
             C.cg[i] = fma(tc, C.cg[i + 1], C.cg[i]);
@@ -947,16 +954,17 @@ __device__ __forceinline__ double cell_sum(const double (&cd)[8], const WalkerK&
     // g in powers of d = x - x_c: (sa d)^j
     double pw = C.sa;
 #pragma unroll
-    for (int j = 1; j <= CELL_M; ++j) {
+    for (int j = 1; j <= 7; ++j) {
         C.cg[j] *= pw;
-        if (j < CELL_M) pw *= C.sa;
+        if (j < 7) pw *= C.sa;
     }
     double acc = 0.0;
 #pragma unroll
     for (int j = CELL_M; j >= 0; --j) {             // (small terms first)
-        double cj = C.cg[0] * C.ch[j];
+        const int i0 = j > 7 ? j - 7 : 0, i1 = j < 7 ? j : 7;
+        double cj = C.cg[i0] * C.ch[j - i0];
 #pragma unroll
-        for (int i = 1; i <= j; ++i) cj = fma(C.cg[i], C.ch[j - i], cj);
+        for (int i = i0 + 1; i <= i1; ++i) cj = fma(C.cg[i], C.ch[j - i], cj);
         acc = fma(cj, cd[1 + j], acc);
     }
     return acc;
@@ -1257,7 +1265,7 @@ __device__ __forceinline__ void zcell_body(const KConst& kc, const ZCells& zc, c
         double tail = 0.0;
         double head = fma(cm1, cd[2], cd[1]);                               // S_0 + c_1 S_1
 #pragma unroll
-        for (int j = 2; j <= CELL_M; ++j) {
+        for (int j = 2; j <= ZCELL_M; ++j) {
             const double cj = fma(a, cm1, b2 * cm2) * (1.0 / j);
             tail = fma(cj, cd[1 + j], tail);
             cm2 = cm1;

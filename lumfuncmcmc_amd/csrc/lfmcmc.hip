@@ -60,7 +60,7 @@ struct lf_ctx {
     unsigned long long* d_forms = nullptr;   // census of the term forms (option "count_forms"), FORM_COUNT slots
     int last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lf_last_launch
     int* d_queue = nullptr;              // FREE: item counters of the persistent workgroups, [tiles][lf::QSTRIDE]
-    // FREE: the catalogue's cells (lf_kernels.h: CELL_M) - {x_c, S_0 .. S_6} per cell, chunks of <= 512 cells of one field
+    // the catalogue's cells (lf_kernels.h: CELL_M, ZCELL_M) - {x_c, S_0 .. S_M} per cell, chunks of 64 (FREE) / 256 (ZEVOL) cells of one field
     double* d_cells = nullptr;           // [ncell][8]
     int* d_cc_start = nullptr;           // [ncchunk] first cell of the chunk
     int* d_cc_len = nullptr;             // [ncchunk] cells in the chunk (<= 64)
@@ -184,6 +184,8 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
     const double rho = wts ? kc.zcell_rho : std::fmin(CELL_RHO_H, CELL_RHO_G / ahi);
     if (!(rho > 0.0)) return LF_OK;
     const size_t per_chunk = wts ? (size_t)BLOCK : 64;
+    const int M = wts ? ZCELL_M : CELL_M;                 // orders kept
+    const size_t rec = (size_t)M + 2;                     // doubles per cell: midpoint, S_0 .. S_M
     std::vector<double> cd;
     std::vector<int> cst, cln, cfl;
     size_t nreal = 0;                    // cells with sources
@@ -198,34 +200,35 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
             kc.kf_first[f] = (int)k0;
             kc.kf_last[f] = (int)k1;
         }
-        const size_t first_cell = cd.size() / 8;
+        const size_t first_cell = cd.size() / rec;
         for (int64_t i = lo; i < hi;) {
             int64_t j = i + 1;
             while (j < hi && x[(size_t)j] - x[(size_t)i] <= 2.0 * rho) ++j;
             const double xc = 0.5 * (x[(size_t)i] + x[(size_t)j - 1]);
             long double S[CELL_M + 1] = {0};
+            static_assert(ZCELL_M <= CELL_M, "S is sized for the larger");
             for (int64_t k = i; k < j; ++k) {
                 const long double dlt = (long double)x[(size_t)k] - (long double)xc;
                 long double pw = wts ? (long double)wts[(size_t)k] : 1.0L;
-                for (int m = 0; m <= CELL_M; ++m) {
+                for (int m = 0; m <= M; ++m) {
                     S[m] += pw;
                     pw *= dlt;
                 }
             }
             cd.push_back(xc);
-            for (int m = 0; m <= CELL_M; ++m) cd.push_back((double)S[m]);
+            for (int m = 0; m <= M; ++m) cd.push_back((double)S[m]);
             i = j;
         }
-        size_t ncf = cd.size() / 8 - first_cell;
+        size_t ncf = cd.size() / rec - first_cell;
         nreal += ncf;
         if (!wts) {
             // lf_free addresses chunk cc at cell 64 cc and masks nothing: pad the field to whole chunks with cells of no
             // sources (all sums 0) at the last real midpoint (inside the tables wherever the real cell is)
             kc.cc_fstart[f] = (int)cst.size();
-            const double xlast = cd[cd.size() - 8];
+            const double xlast = cd[cd.size() - rec];
             while (ncf % 64) {
                 cd.push_back(xlast);
-                for (int m = 0; m <= CELL_M; ++m) cd.push_back(0.0);
+                for (int m = 0; m <= M; ++m) cd.push_back(0.0);
                 ++ncf;
             }
         }
@@ -235,7 +238,7 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
             cfl.push_back(f);
         }
     }
-    const size_t ncell = cd.size() / 8;
+    const size_t ncell = cd.size() / rec;
     if (!wts) {                                                       // (a field without cells starts where the next one does)
         for (int f = nf; f <= MAXF; ++f) kc.cc_fstart[f] = (int)cst.size();
         for (int f = nf - 1; f >= 0; --f)
