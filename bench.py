@@ -57,7 +57,7 @@ def isa_counts(launch, variant):
     """Per-form {flops_per_item, cycles_per_item} of the lf_main instantiation that ran (profiles/isa_counts.json)."""
     doc = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
     vi = {"free": 0, "fixcomp": 1, "zevol": 2}[variant]
-    if launch.get("kind") == 2:
+    if launch.get("kind") == 2:                                       # (capi: the fused form reports kind 2 and "fused")
         key = "lf_free<%d>" % launch["st"]
     else:
         key = "lf_main<%d,%d,%d,%d,%s>" % (vi, launch["st"], launch["tw"], launch["twb"], "true" if launch["compressed"] else "false")

@@ -153,9 +153,15 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * from 64 rows); 0 = always lf_main; 2 = always lf_free (tests).  "free_st": sources per lane of lf_free, 0 (auto: 8
  * for N >= 3e5, else 4), 2, 4 or 8 (tuning runs).  "cells": 1 (default) lets lf_free sum a walker whose every field lies inside the tables over the
  * catalogue's CELLS instead of its sources: runs of flux-neighbouring sources no wider than 2 rho, kept as their
- * midpoint and power sums S_0 .. S_6; on a table piece the term is a polynomial in the flux offset, so a cell's sum is
- * a dot product of its Taylor coefficients with the power sums, exact up to the orders above 6, whose share is below
- * 3e-17 by the choice of rho (from the prior box's largest alpha_C).  0 = every walker over the sources (A/B runs).
+ * midpoint and power sums S_0 .. S_8; on a table piece the term is a polynomial in the flux offset, so a cell's sum is
+ * a dot product of its Taylor coefficients with the power sums, exact up to the orders above 8, whose share is below
+ * 2e-18 by the choice of rho (from the prior box's largest alpha_C).  The z-evolving variant has cells too, in
+ * redshift: what is left of its term per source is a weight times exp of a parabola in z, summed as a series in the
+ * weighted power sums of a run of redshift neighbours (orders above 6 below 1e-17; the cells' width is chosen from the
+ * prior box of L1..L3 so that every walker inside it qualifies).  0 = every walker over the sources (A/B runs).
+ * "fuse": 1 (default) lets lf_free do lf_prepare's and lf_finalize's work itself for plain evaluations - one launch
+ * instead of three, same bits; 0 = three launches (A/B runs; the sampler's steps, lf_lnprob_pieces, the census and
+ * profiling level 2 always take three).  "profile_every": see lf_set_profiling.
  * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
  * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
  * Two keys change what is computed, for SOURCE-SHARDED ranks whose lnprob values are summed (all-reduce): "skip_grid" = 1
@@ -170,12 +176,15 @@ int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
  * exponential, the careful (checked) form, terms of walkers that were not evaluated (outside the prior / already
  * -inf); then (walker, node, field) terms of the grid integral in the general and in the bright form; then
  * (walker, cell) evaluations (option "cells": a cell stands for all the sources of a narrow flux interval).  FREE variant,
- * real catalogue (the other variants and the compressed catalogue leave it at 0).  Synchronises the device. */
+ * real catalogue.  The z-evolving variant counts its own: [8] (walker, cell in redshift) evaluations, [2] terms of its
+ * local form (one exponential per lane of redshift neighbours), [0] per-source exponentials, [6] (walker, node) terms
+ * of its grid.  (The fixed-completeness variant and the compressed catalogue leave it at 0.)  Synchronises the device. */
 int lf_form_counts(lf_ctx *ctx, int64_t counts[9]);
 
 /* Shape of the most recent lf_main launch of this context (measurement only): info[0..7] = sources per lane, walkers
  * per source workgroup and per grid workgroup of the instantiation (template parameters ST, TW, TWB); which kernel ran
- * (0 lf_main, 1 its compressed-catalogue instantiation, 2 lf_free: the persistent kernel of the free variant);
+ * (0 lf_main, 1 its compressed-catalogue instantiation, 2 lf_free: the persistent kernel of the free variant, 3
+ * lf_free in its one-launch form, see "fuse");
  * workgroups in the launch, catalogue chunks, grid chunks, theta rows. */
 int lf_last_launch(const lf_ctx *ctx, int32_t info[8]);
 

@@ -29,6 +29,8 @@ constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalo
 
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
 // (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
+// THROUGH: the partial sum is written through to memory (see pstore in lf_free).
+template <bool THROUGH = false>
 __device__ __forceinline__ void reduce_store512(const double* __restrict__ red, int wlo, int whi, double* __restrict__ out,
                                                 size_t stride, int w0, int chunk, int tid) {
     const int w = tid >> 6, lane = tid & 63;
@@ -37,7 +39,10 @@ __device__ __forceinline__ void reduce_store512(const double* __restrict__ red, 
         double s0 = (row[0] + row[64]) + (row[128] + row[192]);
         double s1 = (row[256] + row[320]) + (row[384] + row[448]);
         const double s = wave_sum_dpp(s0 + s1);
-        if (lane == 63) out[(size_t)(w0 + w) * stride + chunk] = s;
+        if (lane == 63) {
+            if (THROUGH) __hip_atomic_store(out + (size_t)(w0 + w) * stride + chunk, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[(size_t)(w0 + w) * stride + chunk] = s;
+        }
     }
 }
 
@@ -61,12 +66,34 @@ struct FreeArgs {
     int nchC;                 // cell chunks (64 cells; 0: no cells)
     double* partC;            // [B][nslot]: the cells' sums, likewise
     const int* wstat;         // [B]
+    // FUSED instantiation: lf_prepare's and lf_finalize's work is done here, one launch per evaluation (plain lnprob
+    // calls; the sampler's propose / accept steps and the diagnostics keep the three launches)
+    const double* theta;      // [B][ndim]
+    double* out;              // [B] lnprob
+    double* wrec_w;           // the same buffers as the kernel's wrec / wmode arguments, wstat above, wbase: written by the
+    int* wmode_w;             // prologue, read back behind a barrier - through THESE pointers only (the arguments are
+    int* wstat_w;             // const __restrict__: the FUSED instantiation never dereferences them)
+    double* wbase_w;
 };
 
 // CENSUS: the instantiation that counts which form of the term ran (lf_form_counts); the product one has no trace of it
-template <int ST, bool CENSUS>
-__global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeArrays na, const double* __restrict__ wrec,
-                                                 const int* __restrict__ wmode, FreeArgs fa) {
+// FUSED: one launch per evaluation.  Every workgroup of a tile first does lf_prepare's work for the tile's 8 walkers
+// (one wave: 8 lanes per walker, as there; all of the tile's workgroups write the same values to the same records, which
+// spares them a hand-over), and the LAST workgroup to finish a tile (a counter per tile, q[0]) does lf_finalize's for
+// them and leaves the tile's counters at zero for the next launch.  Two kernel boundaries fewer per evaluation:
+// measured 7 + 4.5 us of the 33 an evaluation of 128 rows took.
+template <int ST, bool CENSUS, bool FUSED = false>
+__global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeArrays na, const double* __restrict__ wrec_arg,
+                                                 const int* __restrict__ wmode_arg, FreeArgs fa) {
+    const double* wrec = FUSED ? fa.wrec_w : wrec_arg;
+    const int* wmode = FUSED ? fa.wmode_w : wmode_arg;
+    // A partial sum: in the fused form it is read by a workgroup on another XCD while the launch is still running, so it
+    // is written THROUGH this XCD's L2 (a relaxed store of agent scope: scope bits on the one store - no cache-wide
+    // write-back or invalidate, which is what a fence of that scope costs: measured 154 us per evaluation instead of 30)
+    auto pstore = [](double* p, double v) {
+        if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    };
     __shared__ MathTables tab;
     __shared__ TermTables tt;
     __shared__ __attribute__((aligned(16))) double red[PTW * PB];         // per-walker lane sums of the item in hand
@@ -152,10 +179,17 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         };
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
         const int u = fresh_tid();
+        if (FUSED) {
+            if (u < 64)
+                prepare_lane<false>(kc, StepArgs{}, fa.theta, fa.B, fa.wrec_w, fa.wstat_w, fa.wmode_w, fa.wbase_w, nullptr, 1,
+                                    w0 + (u >> 3), u & 7, u >> 3, reinterpret_cast<double(*)[16]>(red));
+            __threadfence_block();                // the records are read back from memory below, by every wave of this workgroup
+            __syncthreads();
+        }
         if (u < 64) {
             // which walkers of the tile lf_prepare put on the cells (one load per lane); when all of them are, the sources
             // are not touched
-            const bool on = fa.nchC > 0 && u < nw && (fa.wstat[w0 + min(u, nw - 1)] & STAT_CELLS);
+            const bool on = fa.nchC > 0 && u < nw && ((FUSED ? fa.wstat_w : fa.wstat)[w0 + min(u, nw - 1)] & STAT_CELLS);
             const int m = (int)__ballot(on);
             if (u == 0) {
                 scell = m;
@@ -249,9 +283,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 acc = wave_sum_dpp(acc);          // lane 63: the wave's total
                 const int ln = fresh_tid() & 63;
                 double* __restrict__ row = fa.partC + (size_t)(w0 + v) * fa.nslot;
-                if (ln == 63) row[frank] = acc;
+                if (ln == 63) pstore(row + frank, acc);
                 if (frank == 0)
-                    for (int i = fgroup + ln; i < fa.nslot; i += 64) row[i] = 0.0;       // (slots of workgroups this tile does not have)
+                    for (int i = fgroup + ln; i < fa.nslot; i += 64) pstore(row + i, 0.0);       // (slots of workgroups this tile does not have)
             }
         }
         // ---- the grid integral (piece B), the same way: 64 nodes per chunk, one WALKER PER WAVE (lane = node), every wave
@@ -303,9 +337,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 bsum = wave_sum_dpp(bsum);        // lane 63: the wave's total
                 const int ln = fresh_tid() & 63;
                 double* __restrict__ row = fa.partB + (size_t)(w0 + v) * fa.nslot;
-                if (ln == 63) row[frank] = bsum;
+                if (ln == 63) pstore(row + frank, bsum);
                 if (frank == 0)
-                    for (int i = fgroup + ln; i < fa.nslot; i += 64) row[i] = 0.0;
+                    for (int i = fgroup + ln; i < fa.nslot; i += 64) pstore(row + i, 0.0);
             }
         }
         // ---- what is left are the source chunks, for walkers that cannot use the cells: claimed from the per-XCD queues
@@ -462,7 +496,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #endif
                 __syncthreads();                  // [C]
                 t = fresh_tid();
-                reduce_store512(red, 0, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
+                reduce_store512<FUSED>(red, 0, nw, fa.partA, (size_t)fa.nchA, w0, c, t);
                 item = sitem[0];
             }
 #ifdef LF_STAMPS
@@ -473,6 +507,25 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 t_red += __builtin_amdgcn_s_memtime() - tc;
             }
 #endif
+        }
+        if (FUSED) {
+            // This workgroup's partial sums are out - written through, and complete once its waves have waited for their
+            // stores, which the fence makes them do before the barrier; the count (an atomic of agent scope, done at the
+            // memory side) comes after the barrier.  The last of the tile's workgroups to count adds the partials up,
+            // reading them from memory (finalize_wave<true>); the walkers' records it needs are its own copies.
+            __threadfence_block();
+            __syncthreads();
+            if (fresh_tid() == 0) sitem[1] = atomicAdd(q, 1);
+            __syncthreads();
+            if (sitem[1] == fgroup - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int t = fresh_tid(), v = t >> 6;
+                const int nB = fa.nchB > 0 ? fa.nslot : 0, nC = fa.nchC > 0 ? fa.nslot : 0;
+                if (v < nw)
+                    finalize_wave<true>(fa.partA, fa.nchA, fa.nchA, fa.partB, nB, nB, nC > 0 ? fa.partC : nullptr, nC, (int)STAT_CELLS,
+                                        fa.wstat_w, fa.wbase_w, w0 + v, t & 63, AcceptArgs{}, fa.out, nullptr, nullptr);
+                if (t < QSTRIDE) q[t] = 0;        // the tile's counters, for the next launch
+            }
         }
     }
 #ifdef LF_STAMPS

@@ -279,20 +279,21 @@ __device__ __forceinline__ int key_floor(double v) {
 // slow: {count, list...} of the walkers flagged STAT_SLOW, for the rescue workgroups of the compressed-catalogue
 // launch (order = arrival order of the atomics; every walker's sums go to its own slots, so the order is immaterial);
 // lf_finalize resets the count.
-__global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const double* __restrict__ theta, int B,
-                                                 double* __restrict__ wrec, int* __restrict__ wstat,
-                                                 int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
-                                                 int* __restrict__ queue, int nqueue) {
-    __shared__ double sth[8][16];
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gt < nqueue) queue[gt] = 0;                  // item counters of the lf_free launch that follows (8 B threads >= 9 B / 8)
-    const int wq = gt >> 3, f = gt & 7, grp = threadIdx.x >> 3;
+// The work of one lane of lf_prepare: walker wq (8 lanes per walker, lane f = field f), `grp` = the walker's row of the
+// 8 x 16 LDS staging area `sth`.  BLOCK_SYNC: the 64 lanes are a workgroup of their own (lf_prepare) and meet at a
+// barrier; otherwise they are one wave of a larger workgroup (lf_free's fused prologue), in lockstep anyway.
+// nqueue > 0: the launch is lf_free's (the table keys and the cells' flag are wanted).
+template <bool BLOCK_SYNC>
+__device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& sp, const double* __restrict__ theta, int B,
+                                             double* __restrict__ wrec, int* __restrict__ wstat,
+                                             int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
+                                             int nqueue, int wq, int f, int grp, double (*sth)[16]) {
     const bool live = wq < B;
     const int w = live ? wq : B - 1;                 // idle groups replay the last walker, write nothing
     const bool has_f = f < kc.nf;
     // theta row of this walker -> LDS: either the given row, or the stretch-move proposal
     //   y = x_j - (x_j - x_k) z,   z = ((a - 1) u + 1)^2 / a,   j uniform in the other half
-    if (sp.enabled) {
+    if (BLOCK_SYNC && sp.enabled) {                  // (the fused prologue serves plain evaluations only)
         unsigned int rr[4];
         sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
         const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
     } else {
         for (int i = f; i < kc.ndim; i += 8) sth[grp][i] = theta[(size_t)w * kc.ndim + i];
     }
-    __syncthreads();
+    if (BLOCK_SYNC) __syncthreads();
     const double* th = sth[grp];
     double* r = wrec + (size_t)w * REC;
     const double SAFE = -700.0;
@@ -455,6 +456,16 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
         wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0) | (cells ? STAT_CELLS : 0);
         if (slow && slow_list) slow_list[1 + atomicAdd(slow_list, 1)] = w;
     }
+}
+
+__global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const double* __restrict__ theta, int B,
+                                                 double* __restrict__ wrec, int* __restrict__ wstat,
+                                                 int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
+                                                 int* __restrict__ queue, int nqueue) {
+    __shared__ double sth[8][16];
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt < nqueue) queue[gt] = 0;                  // item counters of the lf_free launch that follows (8 B threads >= 9 B / 8)
+    prepare_lane<true>(kc, sp, theta, B, wrec, wstat, wmode, wbase, slow_list, nqueue, gt >> 3, gt & 7, (int)threadIdx.x >> 3, sth);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1418,21 +1429,22 @@ __global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __r
 // finalize: one wave per walker; fixed-order sum of the partials; lnprob = lnprior + A - B.
 // lumfuncmcmc.py:378, :403-409.  Never NaN (emcee raises on NaN): NaN -> -inf.
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,
-                                                  const double* __restrict__ partB, int nchB, int strideB,
-                                                  const double* __restrict__ partR, int nchR, int alt_flag,
-                                                  const int* __restrict__ wstat,
-                                                  const double* __restrict__ wbase, int B, AcceptArgs ap,
-                                                  double* __restrict__ out, double* __restrict__ outA,
-                                                  double* __restrict__ outB, int* __restrict__ slow_list) {
-    const int w = blockIdx.x;
-    if (w >= B) return;
-    if (slow_list && w == 0 && threadIdx.x == 0) slow_list[0] = 0;     // lf_main has consumed the list
-    const int lane = threadIdx.x;
+// One wave finishes walker w.  COHERENT: the partials were written by OTHER workgroups of the launch that is still
+// running, on other XCDs (lf_free's fused epilogue: written through to memory, see there) - read them from there, past
+// this XCD's caches.
+template <bool COHERENT>
+__device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int strideA, const double* partB, int nchB, int strideB,
+                                              const double* partR, int nchR, int alt_flag, const int* wstat, const double* wbase,
+                                              int w, int lane, const AcceptArgs& ap, double* out, double* outA, double* outB) {
+    auto ld = [](const double* p) -> double {
+        if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return *p;
+    };
     double a = 0.0, b = 0.0;
     // piece A of a walker with the alt_flag bit lies in partR: the compressed catalogue's SLOW walkers, summed over the
     // real catalogue by the rescue workgroups (alt_flag = STAT_SLOW); lf_free's walkers summed over cells (STAT_CELLS)
-    const bool resc = partR != nullptr && (wstat[w] & alt_flag);
+    const int st = wstat[w];                          // (COHERENT: the workgroup's own copy, see lf_free.h)
+    const bool resc = partR != nullptr && (st & alt_flag);
     const double* pa = resc ? partR + (size_t)w * nchR : partA + (size_t)w * strideA;
     const double* pb = partB + (size_t)w * strideB;
     if (resc) nchA = nchR;
@@ -1440,18 +1452,17 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int c = lane;
     for (; c + 192 < nchA; c += 256) {
-        a += pa[c];
-        a1 += pa[c + 64];
-        a2 += pa[c + 128];
-        a3 += pa[c + 192];
+        a += ld(pa + c);
+        a1 += ld(pa + c + 64);
+        a2 += ld(pa + c + 128);
+        a3 += ld(pa + c + 192);
     }
-    for (; c < nchA; c += 64) a += pa[c];
+    for (; c < nchA; c += 64) a += ld(pa + c);
     a = (a + a1) + (a2 + a3);
-    for (c = lane; c < nchB; c += 64) b += pb[c];
+    for (c = lane; c < nchB; c += 64) b += ld(pb + c);
     a = wave_sum_dpp(a);                            // totals in lane 63
     b = wave_sum_dpp(b);
     if (lane == 63) {
-        const int st = wstat[w];
         const bool ok = (st & STAT_PRIOR_OK) != 0;
         a += wbase[w];
         if ((st & STAT_NEGINF) || a != a) a = -__builtin_huge_val();
@@ -1462,8 +1473,22 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
         if (outB) outB[w] = ok ? b : __builtin_nan("");
         a = r;                                   // lane 63 keeps the new lnprob for the accept step
     }
-    if (ap.enabled)
+    if (!COHERENT && ap.enabled)                     // (the fused epilogue serves plain evaluations only)
         accept_walker(ap, w, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63)), lane);
+}
+
+__global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,
+                                                  const double* __restrict__ partB, int nchB, int strideB,
+                                                  const double* __restrict__ partR, int nchR, int alt_flag,
+                                                  const int* __restrict__ wstat,
+                                                  const double* __restrict__ wbase, int B, AcceptArgs ap,
+                                                  double* __restrict__ out, double* __restrict__ outA,
+                                                  double* __restrict__ outB, int* __restrict__ slow_list) {
+    const int w = blockIdx.x;
+    if (w >= B) return;
+    if (slow_list && w == 0 && threadIdx.x == 0) slow_list[0] = 0;     // lf_main has consumed the list
+    finalize_wave<false>(partA, nchA, strideA, partB, nchB, strideB, partR, nchR, alt_flag, wstat, wbase, w, (int)threadIdx.x, ap, out,
+                         outA, outB);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -76,6 +76,8 @@ struct lf_ctx {
     std::map<int, ChunkTable> chunks;   // keyed by sources-per-chunk
     std::map<int, ChunkTable> chunks_free;   // the persistent FREE kernel's (lf_free.h): 512 ST sources per chunk, lanes of ST
     int64_t opt_persistent = 1;         // FREE: 1 = lf_free (persistent 512-thread workgroups) for catalogues that fill it
+    int64_t opt_fuse = 1;               // lf_free: prepare and finalize inside the one launch (plain evaluations)
+    bool queue_zero = false;            // d_queue is all zeros (what a fused launch needs and leaves behind)
     int64_t opt_free_st = 0;            // lf_free: sources per lane, 0 = chosen from N and B, else 2 / 4 / 8 (tuning runs)
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
@@ -562,13 +564,15 @@ int free_groups(lf_ctx* c, int slot, int ntiles, int nchA, int nchB, int nchC) {
 }
 
 template <int ST>
-void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa, const lf::NodeArrays& na, lf::FreeArgs fa, hipStream_t s) {
+void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa, const lf::NodeArrays& na, lf::FreeArgs fa, hipStream_t s,
+                 bool fused) {
     // (fa.nslot is set by the caller from free_groups(), which is also what the grid is made of here)
     using namespace lf;
     const dim3 grid((unsigned)(8 * fa.tile_stride));
-    const int info[8] = {ST, PTW, PTW, 2, (int)grid.x, fa.nchA, fa.nchB, B};
+    const int info[8] = {ST, PTW, PTW, fused ? 3 : 2, (int)grid.x, fa.nchA, fa.nchB, B};
     std::memcpy(c->last_launch, info, sizeof(info));
-    if (c->kc.forms) hipLaunchKernelGGL((lf_free<ST, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
+    if (fused) hipLaunchKernelGGL((lf_free<ST, false, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
+    else if (c->kc.forms) hipLaunchKernelGGL((lf_free<ST, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
     else hipLaunchKernelGGL((lf_free<ST, false>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
 }
 
@@ -597,12 +601,23 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
         const int cap = std::max(2 * ntiles * QSTRIDE, 1024);
         LF_HIP(c, hipMalloc((void**)&c->d_queue, (size_t)cap * sizeof(int)));
         c->cap_queue = cap;
+        c->queue_zero = false;
     }
+    // One launch instead of three (lf_free.h: FUSED) for the plain evaluation; the sampler's propose / accept steps, the
+    // two-piece diagnostics, the census and the profile of every launch keep lf_prepare and lf_finalize.
+    const bool fused = c->opt_fuse && !sp.enabled && !ap.enabled && !d_outA && !d_outB && d_out && !c->kc.forms && c->profiling < 2 &&
+                       nchA + nchB > 0;
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->any_enqueued = true;
     c->prof_this = c->profiling > 0 && (c->prof_tick++ % c->opt_profile_every) == 0;
-    {
+    if (fused && !c->queue_zero) {
+        // the tiles' counters start at zero; a fused launch leaves them so, lf_prepare zeroes them for the three-launch form
+        LF_HIP(c, hipMemsetAsync(c->d_queue, 0, (size_t)c->cap_queue * sizeof(int), s));
+        c->queue_zero = true;
+    }
+    if (!fused) {
+        c->queue_zero = false;
         Prof p(c, s, 0);
         hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
                            c->d_wstat, c->d_wmode, c->d_wbase, (int*)nullptr, c->d_queue, ntiles * QSTRIDE);
@@ -610,16 +625,17 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
     const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
     FreeArgs fa{B, ntiles, nchA, nchB, nslot, g8, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
-                c->d_cells, c->d_nodes8, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat};
+                c->d_cells, c->d_nodes8, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat,
+                d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat, c->d_wbase};
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
-            if (st == 8) launch_free<8>(c, slot, B, ntiles, sa, na, fa, s);
-            else if (st == 4) launch_free<4>(c, slot, B, ntiles, sa, na, fa, s);
-            else launch_free<2>(c, slot, B, ntiles, sa, na, fa, s);
+            if (st == 8) launch_free<8>(c, slot, B, ntiles, sa, na, fa, s, fused);
+            else if (st == 4) launch_free<4>(c, slot, B, ntiles, sa, na, fa, s, fused);
+            else launch_free<2>(c, slot, B, ntiles, sa, na, fa, s, fused);
         }
     }
-    {
+    if (!fused) {
         Prof p(c, s, 3);
         const int nB = nchB > 0 ? nslot : 0, nC = nchC > 0 ? nslot : 0;
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nB, nB,
@@ -1363,7 +1379,8 @@ static int host_eval(lf_ctx* c, const double* theta, int B, double* out, double*
     const size_t tb = (size_t)B * c->kc.ndim * sizeof(double);
     std::memcpy(c->h_theta, theta, tb);
     LF_HIP(c, hipMemcpyAsync(c->d_theta, c->h_theta, tb, hipMemcpyHostToDevice, c->stream));
-    rc = enqueue(c, c->d_theta, B, c->d_out, c->d_outA, c->d_outB, c->stream);
+    // (the two pieces only when they are asked for: a plain evaluation then takes lf_free's one-launch form)
+    rc = enqueue(c, c->d_theta, B, c->d_out, outA ? c->d_outA : nullptr, outB ? c->d_outB : nullptr, c->stream);
     if (rc != LF_OK) return rc;
     const size_t ob = (size_t)B * sizeof(double);
     LF_HIP(c, hipMemcpyAsync(c->h_out, c->d_out, ob, hipMemcpyDeviceToHost, c->stream));
@@ -1555,6 +1572,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
             LF_HIP(c, hipMemset(c->d_forms, 0, lf::FORM_COUNT * sizeof(unsigned long long)));
         }
         c->kc.forms = value != 0 ? c->d_forms : nullptr;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "fuse") == 0) {
+        c->opt_fuse = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "profile_every") == 0) {

@@ -85,7 +85,7 @@ def analyse(s):
     out = {}
     for name, lines in kernels(s):
         m = re.search(r"lf_mainILi(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)", name)
-        mf = re.search(r"lf_freeILi(\d+)ELb0", name)          # the persistent FREE kernel, product instantiation
+        mf = re.search(r"lf_freeILi(\d+)ELb0ELb1E", name)     # the persistent FREE kernel, product (fused) instantiation
         if mf:
             st = int(mf.group(1))
             key = "lf_free<%d>" % st

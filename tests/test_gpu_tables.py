@@ -136,6 +136,40 @@ def test_census_adds_up():
     assert fc["node_general"] + fc["node_bright"] == 39 * 101 * 101 * 5, fc
 
 
+@pytest.mark.parametrize("n,B,cells", [(60001, 597, 1), (60001, 597, 0), (400003, 130, 1), (400003, 9, 0), (1000000, 128, 1)])
+def test_one_launch_form_equals_the_three_launch_form(n, B, cells):
+    """lf_free doing lf_prepare's and lf_finalize's work itself (lf_free.h: FUSED - the tile's walkers prepared by every
+    workgroup of the tile, the partial sums written through to memory and added up by the last workgroup to finish the
+    tile) against the three launches: the same partial sums in the same slots added in the same order, so the same
+    bits.  Several tiles per group of workgroups, ragged tiles, -inf rows and rows outside the prior, walkers on the
+    cells and on the sources, twice in a row (the tile counters must come back to zero)."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", n, seed=61)
+    ctx = LFContext(inp, max_batch=max(B, 64))
+    ctx.set_option("persistent", 2)
+    ctx.set_option("cells", cells)
+    th = _rows(B, 62, wide=True)
+    th[min(5, B - 1), 0] = 40.2
+    th[min(7, B - 1), 1] = 6.0
+    ctx.set_option("fuse", 0)
+    lp0 = ctx.lnprob_batch(th)
+    assert not ctx.last_launch()["fused"]
+    ctx.set_option("fuse", 1)
+    lp1 = ctx.lnprob_batch(th)
+    assert ctx.last_launch()["fused"] and ctx.last_launch()["kernel"].startswith("lf_free")
+    lp2 = ctx.lnprob_batch(th[::-1].copy())[::-1]
+    lp3 = ctx.lnprob_batch(th)
+    a, b = ctx.lnprob_pieces(th)                        # (the diagnostics keep the three launches)
+    assert not ctx.last_launch()["fused"]
+    ctx.close()
+    assert not np.isnan(lp0).any() and np.isinf(lp0).sum() >= 2
+    np.testing.assert_array_equal(lp1, lp0)
+    np.testing.assert_array_equal(lp3, lp0)
+    fin = np.isfinite(lp0)
+    np.testing.assert_allclose(lp2[fin], lp0[fin], rtol=1e-13)      # (other tiles, other slots: another order of the sums)
+    assert np.array_equal(np.isinf(lp2), np.isinf(lp0))
+
+
 # ---------------------------------------------------------------------------------------------- cells
 @pytest.mark.parametrize("n,nf,B", [(400003, 5, 96), (1000000, 5, 130), (60011, 3, 33), (33000, 8, 9), (6000, 8, 9)])
 def test_cells_equal_the_sum_over_sources(n, nf, B):
