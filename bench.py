@@ -246,6 +246,8 @@ class Leg(object):
             ctx.set_option("tables", 0)
         if args.no_cells:
             ctx.set_option("cells", 0)
+        if args.no_fuse:
+            ctx.set_option("fuse", 0)
         self.ndim = ctx.ndim
         # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
         self.theta_all = synth.walkers(args.variant, self.half * nblk, seed=seed).reshape(nblk, self.half, self.ndim)
@@ -375,18 +377,22 @@ def roofline_of(args, leg, model, kt, dt):
     if cnt.get("cell", 0.0) > 0.0 and cnt.get("table", 0.0) + cnt.get("general", 0.0) == 0.0:
         # every walker was summed over the catalogue's cells: 64 B per cell are streamed, not the sources
         alg_bytes = cnt["cell"] / max(rows, 1) * 64 + rows * 8 * (leg.ndim + 1)
-    traffic = None
+    traffic = rocprof_ms = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tf) and leg.world == 1:
+    if os.path.exists(tf) and leg.world == 1 and not (args.no_cells or args.no_fuse or args.no_tables or args.no_specialise or args.compress):
         try:
-            traffic = json.load(open(tf)).get("%s_n%d_b%d" % (variant, nsrc, rows), {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tf)).get("%s_n%d_b%d" % (variant, nsrc, rows), {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            # (the committed rocprofv3 --kernel-trace --stats run of this same command: the kernel between its own begin
+            # and end; the event pair here also spans the dispatch of the launch)
+            rocprof_ms = ent.get("rocprofv3_avg_launch_ns") and ent["rocprofv3_avg_launch_ns"] * 1e-6
         except Exception:
-            traffic = None
+            traffic = rocprof_ms = None
     ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12
     ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
     return {"bound": "valu_fp64", "kernel": kernel, "achieved": ach_tf,
             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
-            "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches,
+            "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches, "rocprofv3_avg_launch_ms": rocprof_ms,
             "launches_timed": "every %d-th of the timed region's %d, HIP events on the launch stream" % (max(args.profile_every, 1), 2 * args.steps),
             "measured_on": "rank 0",
             "launch": launch, "terms_per_launch": terms,
@@ -422,6 +428,7 @@ def main():
     ap.add_argument("--taper", action="store_true", help="quarter-size tail tiles, see the taper option")
     ap.add_argument("--no-extras", action="store_true", help="only the timed loop: no device-sampler / compressed-catalogue / strong-scaling legs (profiling runs)")
     ap.add_argument("--no-specialise", action="store_true", help="A/B: without the chunk-level term specialisation")
+    ap.add_argument("--no-fuse", action="store_true", help="A/B: three launches per evaluation (lf_prepare, lf_free, lf_finalize) instead of one")
     ap.add_argument("--no-cells", action="store_true", help="A/B: every walker summed over the sources, not over the catalogue's cells")
     ap.add_argument("--no-tables", action="store_true", help="A/B: the general form of the free term only (no g/h tables)")
     ap.add_argument("--force-collective", action="store_true",
@@ -525,7 +532,7 @@ def main():
                           "walkers_total": Wtot, "variant": args.variant, "shard": shard if world > 1 else "none",
                           "parallelism": par},
                "roofline": roofline_of(args, leg, model, kt, dt)}
-    ab = [n for n in ("no_cells", "no_tables", "no_specialise", "compress", "taper") if getattr(args, n)]
+    ab = [n for n in ("no_cells", "no_fuse", "no_tables", "no_specialise", "compress", "taper") if getattr(args, n)]
     if ab and rank == 0:
         res["config"]["ab_options"] = ab                    # an A/B run, not the default path
     if world > 1 and scaling == "weak" and not args.no_extras:

@@ -23,11 +23,14 @@ python3 bench.py $b --nsrc 1000 --walkers 32 > $out/bench_n1e3.json 2>/dev/null
 python3 bench.py $b --variant zevol > $out/bench_zevol.json 2>/dev/null
 python3 bench.py $b --variant zevol --no-cells > $out/bench_zevol_nocells.json 2>/dev/null
 python3 bench.py $b --variant fixcomp > $out/bench_fixcomp.json 2>/dev/null
+python3 bench.py $b --no-fuse > $out/bench_nofuse.json 2>/dev/null
 python3 bench.py $b --no-cells > $out/bench_nocells.json 2>/dev/null
 python3 bench.py $b --no-cells --no-tables > $out/bench_nocells_notables.json 2>/dev/null
 python3 bench.py $b --profile-every 1 > $out/bench_events_every_launch.json 2>/dev/null
 python3 bench.py $b --profile-level 0 > $out/bench_no_events.json 2>/dev/null
 python3 tools/stamps.py > $out/stamps.txt 2>&1
 python3 tools/time_parts.py --sets "default;skip_grid=1;cells=0;cells=0,skip_grid=1" > $out/time_parts.txt 2>&1
+python3 tools/time_parts.py --rows 256 --sets "default;skip_grid=1" >> $out/time_parts.txt 2>&1
+python3 tools/time_parts.py --variant zevol --sets "default;cells=0" >> $out/time_parts.txt 2>&1
 python3 tools/call_period.py > $out/call_period.txt 2>&1
 ls $out

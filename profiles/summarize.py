@@ -36,15 +36,26 @@ json.dump(summary, open(os.path.join(here, "%s_pmc.json" % tag), "w"), indent=1,
 
 # the dominant kernel = the direct lf_main / lf_free (the bench also runs a census instantiation and, with extras, the
 # compressed-catalogue one, whose launches read a few hundred KB): the one with the largest fetch
-dom = sorted([k for k in summary if ("lf_main" in k or ("lf_free" in k and "true>" not in k)) and "FETCH_SIZE" in summary[k]],
-             key=lambda k: -summary[k]["FETCH_SIZE"])
+def product(k):                # lf_main, or lf_free<ST, false, .>: not the census instantiation lf_free<ST, true, false>
+    import re
+    return "lf_main" in k or re.search(r"lf_free<\d+, false", k) is not None
+
+
+dom = sorted([k for k in summary if product(k) and "FETCH_SIZE" in summary[k]], key=lambda k: -summary[k]["_launches_sampled"])
 if dom:
     fetch_kb, write_kb = summary[dom[0]]["FETCH_SIZE"], summary[dom[0]].get("WRITE_SIZE", 0.0)
     tf = os.path.join(here, "hbm_traffic.json")
     d = json.load(open(tf)) if os.path.exists(tf) else {}
-    d["%s_n%d_b%d" % (variant, nsrc, rows)] = {
+    # rocprofv3 --stats average of the same kernel (bench.py prints it next to its own event timing)
+    avg_ns = None
+    for r in csv.DictReader(open(os.path.join(here, "%s_kernel_stats.csv" % tag))):
+        if r["Name"].split("(")[0].replace("void ", "") == dom[0]:
+            avg_ns = float(r["AverageNs"])
+    suffix = sys.argv[6] if len(sys.argv) > 6 else ""          # (A/B runs of the same shape: their own entry)
+    d["%s_n%d_b%d%s" % (variant, nsrc, rows, suffix)] = {
         "kernel": dom[0], "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
         "fetch_correction": 2.0,
-        "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024 + write_kb * 1024, "source": "profiles/%s_pmc.json" % tag}
+        "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024 + write_kb * 1024, "source": "profiles/%s_pmc.json" % tag,
+        "rocprofv3_avg_launch_ns": avg_ns, "stats": "profiles/%s_kernel_stats.csv" % tag}
     json.dump(d, open(tf, "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1)[:1500])
