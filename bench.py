@@ -376,7 +376,12 @@ def roofline_of(args, leg, model, kt, dt):
     alg_bytes = nsrc * BYTES_PER_SOURCE[variant] + rows * 8 * (leg.ndim + 1)
     if cnt.get("cell", 0.0) > 0.0 and cnt.get("table", 0.0) + cnt.get("general", 0.0) == 0.0:
         # every walker was summed over the catalogue's cells: 64 B per cell are streamed, not the sources
-        alg_bytes = cnt["cell"] / max(rows, 1) * 64 + rows * 8 * (leg.ndim + 1)
+        # (records of 80 B, free completeness: midpoint + 9 power sums; 64 B, z-evolving: midpoint + 7) - plus the grid's
+        # nodes, read once per launch: 64-B records (free) or five arrays of doubles (z-evolving)
+        nodes = cnt.get("node_general", 0.0) + cnt.get("node_bright", 0.0)
+        nodes = nodes / max(rows, 1) / (leg.ctx.nf if variant == "free" else 1)
+        alg_bytes = cnt["cell"] / max(rows, 1) * (80 if variant == "free" else 64) + nodes * (64 if variant == "free" else 40) \
+            + rows * 8 * (leg.ndim + 1)
     traffic = rocprof_ms = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf) and leg.world == 1 and not (args.no_cells or args.no_fuse or args.no_tables or args.no_specialise or args.compress):
