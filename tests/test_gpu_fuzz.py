@@ -116,3 +116,56 @@ def test_random_large_catalogue_compressed(seed):
     print("seed %d %s n=%d nf=%d: compressed vs direct %.2e" % (seed, variant, n, nf, rel))
     assert rel < 1e-13
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configuration_cells(seed):
+    """Catalogues big enough for cells (free completeness: in log-flux, through lf_free; z-evolving: in redshift, through
+    lf_main), ragged fields some of them too small for any cell, random prior-box widths (they set the cells' width),
+    rows outside the prior / in the underflow zone / NaN: against the sum over the sources of the same build ("cells" = 0,
+    all rows), against the oracle (the first rows), and - free completeness - one launch against three, bit for bit."""
+    from lumfuncmcmc_amd.capi import LFContext
+    rng = np.random.default_rng(5000 + seed)
+    variant = ("free", "zevol")[seed % 2]
+    nf = int(rng.integers(1, 9))
+    # (the z-evolving cells are narrow - their width covers the whole prior box of L1..L3 - so they need more sources)
+    n = int(rng.choice([33000, 60000, 90001, 150000] if variant == "free" else [200000, 300001, 400000]))
+    inp = make_inputs(variant, n, seed=300 + seed, S=int(rng.integers(6, 40)), fix_sch_al=bool(rng.integers(0, 2)), nf=nf,
+                      pivots=(1.18, 1.36, 1.54) if seed % 4 < 2 else (1.20, 1.53, 1.86))
+    if variant == "free":
+        cuts = np.sort(rng.integers(0, n + 1, nf - 1)) if nf > 1 else np.array([], dtype=int)
+        inp["field_ind"] = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    inp["lims"] = {k: list(v) for k, v in inp["lims"].items()}
+    if variant == "free" and seed % 3 == 0:
+        inp["lims"]["alpha"] = [1.0, float(rng.uniform(7.0, 30.0))]        # narrower cells
+    B = int(rng.choice([7, 9, 33, 130]))
+    th = synth.walkers(variant, B, seed=seed + 21, fix_sch_al=inp["fix_sch_al"], nf=nf)
+    if B > 3:
+        th[0, 0] = 40.2
+        th[1, 1] = 5.5
+        th[2, -1] = np.nan
+    nref = min(B, 10)
+    ref = O.lnprob_batch(inp, th[:nref])
+    ctx = LFContext(inp, max_batch=max(B, 64))
+    if variant == "free":
+        ctx.set_option("persistent", 2)
+    ctx.set_option("count_forms", 1)
+    ctx.lnprob_pieces(th)
+    ncell = ctx.form_counts()["cell"]
+    ctx.set_option("count_forms", 0)
+    lp1 = ctx.lnprob_batch(th)
+    fused = ctx.last_launch()["fused"]
+    ctx.set_option("fuse", 0)
+    lp2 = ctx.lnprob_batch(th)
+    ctx.set_option("fuse", 1)
+    ctx.set_option("cells", 0)
+    lp0 = ctx.lnprob_batch(th)
+    ctx.close()
+    # (z-evolving with the close pivots: the box allows slopes so steep that a cell would hold under four sources - none made)
+    assert ncell > 0 or (variant == "zevol" and seed % 4 < 2), "seed %d: no cells" % seed
+    assert fused == (variant == "free")
+    np.testing.assert_array_equal(lp1, lp2)
+    assert np.array_equal(np.isinf(lp1), np.isinf(lp0)) and not np.isnan(lp1).any()
+    fin = np.isfinite(lp0)
+    np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=1e-13)
+    compare_rows(lp1[:nref], ref, inp, th[:nref], RTOL, "seed %d cells" % seed)

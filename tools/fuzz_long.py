@@ -20,6 +20,11 @@ for seed in range(a, a + (b - a) // 10):
         F.test_random_large_catalogue_compressed(seed)
     except Exception as e:
         bad.append(("large", seed, repr(e)[:200]))
-print("seeds %d..%d: %d failures in %.0f s" % (a, b, len(bad), time.time() - t))
+for seed in range(a, a + (b - a) // 5):
+    try:
+        F.test_random_configuration_cells(seed)
+    except Exception as e:
+        bad.append(("cells", seed, repr(e)[:200]))
+print("seeds %d..%d: %d failures in %.0f s" % (a, b, len(bad), time.time() - t), flush=True)
 for x in bad:
     print(x)
