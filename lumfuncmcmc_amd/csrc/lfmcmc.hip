@@ -1180,7 +1180,8 @@ int build(lf_ctx* c, const lf_desc* d) {
     if ((rc = upload(c, &c->d_U, U.data(), (size_t)N)) != LF_OK) return rc;
 
     // ---- grid-node tables.  trapz weights from the actual spacings (scipy trapz = sum d*(y1+y0)/2)
-    const size_t nn = (size_t)S * S;
+    size_t nn = (size_t)S * S;
+    const size_t nn2 = nn;               // (the lattice; nn becomes S below when the fixed-completeness grid collapses to its rows)
     std::vector<double> G(nn), PG(nn), W(nn), a3(nn, 0.0), a4(nn, 0.0), wz(S);
     for (int k = 0; k < S; ++k) {
         const double dl = k > 0 ? d->zarr[k] - d->zarr[k - 1] : 0.0;
@@ -1204,7 +1205,7 @@ int build(lf_ctx* c, const lf_desc* d) {
                 W[g] = w * d->volume_part[k];
             } else {
                 double s = 0.0;
-                for (int f = 0; f < nf; ++f) s += d->integ_part[(size_t)f * nn + g];
+                for (int f = 0; f < nf; ++f) s += d->integ_part[(size_t)f * nn2 + g];
                 W[g] = w * s;
                 if (d->variant == LF_ZEVOL) {
                     a3[g] = d->zarr[k];
@@ -1235,6 +1236,32 @@ int build(lf_ctx* c, const lf_desc* d) {
                 c->h_Dk[k] = std::log10(4.0 * M_PI * dlcm * dlcm);
                 c->h_ck[k] = wz[k] * d->volume_part[k];
             }
+        }
+    }
+    if (d->variant == LF_FIXCOMP && !std::getenv("LF_NO_COLLAPSE_GRID")) {        // (the variable: A/B runs and the test of this step)
+        // Fixed completeness: the integrand at node (j, k) is T_w(L_jk) W_jk with everything but the Schechter function
+        // T folded into W.  When every redshift column has the same luminosity nodes (the constructor clips the columns'
+        // lower ends to the catalogue's faintest luminosity: with min_comp_frac = 0 all of them) T depends on the row only
+        // and the double sum is sum_j T_w(L_j) (sum_k W_jk): S nodes instead of S^2, exactly - the trapezoid rule's sums
+        // in another order.  Row sums in extended precision.
+        bool sep = true;
+        for (int j = 0; j < S && sep; ++j)
+            for (int k = 1; k < S; ++k)
+                if (d->logL[(size_t)j * S + k] != d->logL[(size_t)j * S]) {
+                    sep = false;
+                    break;
+                }
+        if (sep) {
+            for (int j = 0; j < S; ++j) {
+                long double rs = 0.0L;
+                for (int k = 0; k < S; ++k) rs += (long double)W[(size_t)j * S + k];
+                G[(size_t)j] = G[(size_t)j * S];
+                PG[(size_t)j] = PG[(size_t)j * S];
+                W[(size_t)j] = (double)rs;
+                a3[(size_t)j] = a4[(size_t)j] = 0.0;
+            }
+            nn = (size_t)S;
+            c->nnodes = S;
         }
     }
     if ((rc = upload(c, &c->d_G, G.data(), nn)) != LF_OK) return rc;

@@ -405,3 +405,40 @@ def test_zevol_cells_equal_the_sum_over_sources(n, nf, zslices, pivots, rows):
     if ref is not None:
         f6 = np.isfinite(ref)
         np.testing.assert_allclose(lp1[:6][f6], ref[f6], rtol=RTOL)
+
+
+@pytest.mark.parametrize("sep", [True, False])
+def test_fixcomp_grid_summed_over_its_rows(sep, monkeypatch):
+    """Fixed completeness, every redshift column on the same luminosity nodes (what the reference's constructor makes
+    with min_comp_frac = 0): the integrand is the Schechter function of the ROW times a weight, so lf_create sums the
+    weights over the columns and the kernel integrates S nodes instead of S^2 - the same sums in another order.  When
+    the columns differ (min_comp_frac > 0: their lower ends follow the completeness limit) the full lattice stays.
+    Against the full lattice of the same build (LF_NO_COLLAPSE_GRID) and the oracle."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("fixcomp", 30000, seed=71)
+    S = int(np.asarray(inp["zarr"]).shape[0])
+    if not sep:
+        lo = np.asarray(inp["logL"])[0, 0]
+        inp["logL"] = np.stack([np.linspace(lo + 0.3 * k / S, synth.LH, S) for k in range(S)], axis=1)
+    th = synth.walkers("fixcomp", 40, seed=72)
+    th[3, 0] = 40.2
+    ctx = LFContext(inp)
+    a1, b1 = ctx.lnprob_pieces(th)
+    lp = ctx.lnprob_batch(th[:10])
+    nodes1 = ctx.last_launch()["chunks_b"]
+    ctx.close()
+    monkeypatch.setenv("LF_NO_COLLAPSE_GRID", "1")
+    ctx = LFContext(inp)
+    a0, b0 = ctx.lnprob_pieces(th)
+    nodes0 = ctx.last_launch()["chunks_b"]
+    ctx.close()
+    assert nodes0 == (S * S + 255) // 256 and nodes1 == ((S + 255) // 256 if sep else nodes0)
+    np.testing.assert_array_equal(a1, a0)
+    fin = np.isfinite(b0)
+    np.testing.assert_allclose(b1[fin], b0[fin], rtol=1e-13)
+    if not sep:
+        np.testing.assert_array_equal(b1, b0)
+    ref = O.lnprob_batch(inp, th[:10])
+    f = np.isfinite(ref)
+    assert np.array_equal(f, np.isfinite(lp))
+    np.testing.assert_allclose(lp[f], ref[f], rtol=RTOL)
