@@ -189,11 +189,17 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         if (u < 64) {
             // which walkers of the tile lf_prepare put on the cells (one load per lane); when all of them are, the sources
             // are not touched
-            const bool on = fa.nchC > 0 && u < nw && ((FUSED ? fa.wstat_w : fa.wstat)[w0 + min(u, nw - 1)] & STAT_CELLS);
+            const int st = (FUSED ? fa.wstat_w : fa.wstat)[w0 + min(u, nw - 1)];
+            const bool on = fa.nchC > 0 && u < nw && (st & STAT_CELLS);
+            // ... and which need the sources at all: not the ones outside the prior or already known to be -inf (their
+            // lnprob is -inf whatever the sums are: lf_finalize).  A stretch-move ensemble puts such a proposal into nearly
+            // every tile of 8, and each used to cost its tile a pass over the whole catalogue with every term skipped.
+            const bool need = u < nw && !on && (st & STAT_PRIOR_OK) && !(st & STAT_NEGINF);
             const int m = (int)__ballot(on);
+            const unsigned long long mneed = __ballot(need);
             if (u == 0) {
                 scell = m;
-                no_src = fa.nchC > 0 && m == (1 << nw) - 1;
+                no_src = mneed == 0ull;
                 sitem[0] = grab();
             }
         }

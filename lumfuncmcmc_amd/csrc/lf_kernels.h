@@ -1330,8 +1330,10 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
             nw_ = min(tl.tws, B - w0_);
         }
         const int lane = threadIdx.x & 63;
-        const int flagged = lane < nw_ ? (zc.wstat[w0_ + lane] & STAT_CELLS) : STAT_CELLS;      // (tiles are at most 16 walkers)
-        if (__builtin_amdgcn_ballot_w64(flagged == 0) == 0) return;                             // (the same in every wave)
+        // (walkers outside the prior or already known to be -inf need no sums either: lf_finalize)
+        const int st_ = lane < nw_ ? zc.wstat[w0_ + lane] : STAT_CELLS;                         // (tiles are at most 16 walkers)
+        const bool need = !(st_ & STAT_CELLS) && (st_ & STAT_PRIOR_OK) && !(st_ & STAT_NEGINF);
+        if (__builtin_amdgcn_ballot_w64(need) == 0) return;                                     // (the same in every wave)
     }
     load_tables_256(&tab);
     __syncthreads();
