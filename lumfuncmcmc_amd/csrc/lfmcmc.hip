@@ -656,7 +656,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     // the persistent kernel takes the free variant's direct path whenever the catalogue can fill it and no launch
     // geometry of lf_main was asked for explicitly
     if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
-        !(c->opt_compress && c->cmp.built) && (c->N >= 32768 || c->opt_persistent == 2)) {
+        !(c->opt_compress && c->cmp.built) && (c->N >= 8192 || c->opt_persistent == 2)) {
         // Measured crossover (tools/time_parts.py on a warmed-up device, lf_main / lf_free in us; 128 rows: N = 5e4 33 / 37,
         // 7e4 36 / 38, 1e5 40 / 40, 1.8e5 49 / 49, 2.5e5 60 / 56, 5e5 95 / 72, 1e6 168 / 112; N = 1e6 with 16 / 32 / 64 /
         // 256 rows: 29 / 79, 50 / 56, 91 / 72, 327 / 205; N = 1e5 with 512 rows: 127 / 120): the persistent kernel wins
@@ -665,10 +665,15 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         // With the catalogue's cells (the normal case) piece A costs next to nothing and the kernel takes 22-34 us up to
         // 128 rows whatever N is (the grid integral): it wins from N x rows ~ 1e7 (lf_main / lf_free, 128 rows: N = 5e4
         // 32 / 34, 1e5 40 / 33, 2.5e5 60 / 33; N = 1e6 with 16 / 32 / 64 rows: 30 / 24, 50 / 25, 94 / 30; N = 1e5 with
-        // 32 / 512 rows: 16 / 25, 126 / 88).
+        // 32 / 512 rows: 16 / 25, 126 / 88).  A plain evaluation is ONE launch in lf_free against three: the period of
+        // back-to-back evaluations (tools/sweep_small.sh, lf_main / lf_free in us, 128 rows: N = 1e4 29.3 / 26.1, 3e4 37.0 /
+        // 26.4, 7.8e4 44.4 / 26.9; 16 rows, where the Python caller binds both: 17-18 / 18.5-18.9) moves the crossover
+        // down to N x rows ~ 1.2e6 from 32 rows.
         const int64_t ntiles = (B + PTW - 1) / PTW;
         const int64_t items = free_shape(c).items_per_tile * ntiles;
-        const bool wins = c->kc.cells ? c->N * (int64_t)B >= 10000000 : items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1);
+        const bool plain = !sp.enabled && !ap.enabled && !d_outA && !d_outB && c->opt_fuse;
+        const bool wins = c->kc.cells ? (plain ? c->N * (int64_t)B >= 1200000 && B >= 32 : c->N * (int64_t)B >= 10000000)
+                                      : items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1);
         if (wins || c->opt_persistent == 2 || c->opt_free_st)
             return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     }

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--rows", type=int, default=128)
     ap.add_argument("--calls", type=int, default=4000)
     ap.add_argument("--variant", default="free")
+    ap.add_argument("--opts", default="", help="context options, k=v,k=v")
+    ap.add_argument("--levels", default="0,1,2,0", help="profiling levels to run")
     ap.add_argument("--default-stream", action="store_true", help="launch on the null stream instead of a stream of our own")
     a = ap.parse_args()
     model = bench.build_model(a.variant, a.nsrc, 2 * a.rows, 0)
@@ -27,7 +29,10 @@ def main():
     if not a.default_stream:
         st = torch.cuda.Stream()
         torch.cuda.set_stream(st)
-    for level in (0, 1, 2, 0):
+    for kv in filter(None, a.opts.split(",")):
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    for level in [int(x) for x in a.levels.split(",")]:
         ctx.set_profiling(level)
         for rep in range(2):
             torch.cuda.synchronize()
@@ -38,7 +43,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             ctx.kernel_times()
-        print("profiling %d: %.2f us per call (host enqueue %.2f us per call)" % (level, 1e6 * dt / a.calls, 1e6 * th_host / a.calls), flush=True)
+        print("profiling %d: %.2f us per call (host enqueue %.2f us per call) %s" % (level, 1e6 * dt / a.calls, 1e6 * th_host / a.calls,
+                                                                                   ctx.last_launch()["kernel"] + (" fused" if ctx.last_launch()["fused"] else "")), flush=True)
     ctx.set_profiling(0)
 
 
