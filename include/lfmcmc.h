@@ -177,8 +177,8 @@ int lf_set_option(lf_ctx *ctx, const char *key, int64_t value);
  * -inf); then (walker, node, field) terms of the grid integral in the general and in the bright form; then
  * (walker, cell) evaluations (option "cells": a cell stands for all the sources of a narrow flux interval).  FREE variant,
  * real catalogue.  The z-evolving variant counts its own: [8] (walker, cell in redshift) evaluations, [2] terms of its
- * local form (one exponential per lane of redshift neighbours), [0] per-source exponentials, [6] (walker, node) terms
- * of its grid.  (The fixed-completeness variant and the compressed catalogue leave it at 0.)  Synchronises the device. */
+ * local form (one exponential per lane of redshift neighbours), [0] per-source exponentials, [4] terms of the careful
+ * form, [6] (walker, node) terms of its grid.  (The fixed-completeness variant and the compressed catalogue leave it at 0.)  Synchronises the device. */
 int lf_form_counts(lf_ctx *ctx, int64_t counts[9]);
 
 /* Shape of the most recent lf_main launch of this context (measurement only): info[0..7] = sources per lane, walkers

@@ -781,6 +781,7 @@ __device__ __forceinline__ void srcsum_body(const KConst& kc, const SrcArrays& s
             // are re-read from memory inside a rolled loop so that this path adds no register pressure
             // to the fast one.
             const double* __restrict__ r = wrec + wi(w) * REC;
+            if (VARIANT == LF_ZEVOL && !CMP && kc.forms && tid == 0) atomicAdd(kc.forms + FORM_CAREFUL, (unsigned long long)n);
             if (VARIANT == LF_FREE) {
                 nxA = rn[R_ALPHAC];
                 nxC = rn[RF(fld, F_CA)];
@@ -1244,7 +1245,9 @@ struct ZCells {
     int nchC;                   // 0: no cells
     double* partC;              // [B][nchC]
     const int* wstat;           // [B]
+    int nwork;                  // workers that share the per-source items (lf_main)
 };
+constexpr int ZCELL_MAXB = 16384;         // walkers whose "needs the sources" bits have a bit of their own in a worker's LDS
 
 // one item: cell chunk cc x walkers w0 .. w0+nw-1 (a thread = a cell)
 template <int TW>
@@ -1315,30 +1318,64 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
     }
     constexpr bool ZC = VARIANT == LF_ZEVOL && !CMP;
     const int nsrc_wg = nchA * (tl.ntiles + tl.ntiles_s);
-    if (ZC && zc.nchC > 0 && id >= nblkB && id < nblkB + nsrc_wg) {
-        // a per-source workgroup whose walkers are all summed over the cells has nothing to do: leave before the prologue
-        // (the same tile arithmetic as below)
-        const int sid = id - nblkB, nbig_ = nchA * tl.ntiles;
-        int w0_, nw_;
-        if (sid < nbig_) {
-            const int wg = xcd_renumber(sid, nbig_);
-            w0_ = (wg % tl.ntiles) * tl.tw;
-            nw_ = min(tl.tw, tl.B1 - w0_);
+    // item `sid` of the per-source part -> chunk, first walker, walkers
+    auto src_item = [&](int sid, int& c, int& w0, int& nw) {
+        const int nbig = nchA * tl.ntiles;
+        if (sid < nbig) {
+            const int wg = xcd_renumber(sid, nbig);
+            c = wg / tl.ntiles;
+            w0 = (wg - c * tl.ntiles) * tl.tw;
+            nw = min(tl.tw, tl.B1 - w0);
         } else {
-            const int wg = xcd_renumber(sid - nbig_, nchA * tl.ntiles_s);
-            w0_ = tl.B1 + (wg % tl.ntiles_s) * tl.tws;
-            nw_ = min(tl.tws, B - w0_);
+            const int wg = xcd_renumber(sid - nbig, nchA * tl.ntiles_s);
+            c = wg / tl.ntiles_s;
+            w0 = tl.B1 + (wg - c * tl.ntiles_s) * tl.tws;
+            nw = min(tl.tws, B - w0);
         }
-        const int lane = threadIdx.x & 63;
-        // (walkers outside the prior or already known to be -inf need no sums either: lf_finalize)
-        const int st_ = lane < nw_ ? zc.wstat[w0_ + lane] : STAT_CELLS;                         // (tiles are at most 16 walkers)
-        const bool need = !(st_ & STAT_CELLS) && (st_ & STAT_PRIOR_OK) && !(st_ & STAT_NEGINF);
-        if (__builtin_amdgcn_ballot_w64(need) == 0) return;                                     // (the same in every wave)
+    };
+    if constexpr (VARIANT != LF_FREE && !CMP) if (zc.nwork > 0) {
+        // Z-evolving with cells, fixed completeness: the per-source items are normally all idle (every walker inside the
+        // prior is summed over the cells; the fixed-completeness sum is closed-form unless a walker is on the careful path).
+        // Instead of one workgroup per item - 3920 of them at 10^6 sources and 128 rows, each dispatched only to leave,
+        // 0.8 ns apiece - `zc.nwork` workers share the items, and a worker first looks at the walkers' flags once (a bit per
+        // walker in LDS) and leaves at once when no walker needs the sources.  (lf_finalize ignores the per-source
+        // partials of the walkers that did not need them.)
+        __shared__ unsigned needbits[ZCELL_MAXB / 32];
+        __shared__ int anyneed;
+        if (id >= nblkB && id < nblkB + zc.nwork) {
+            const int tid = threadIdx.x;
+            if (tid == 0) anyneed = 0;
+            for (int i = tid; i < ZCELL_MAXB / 32; i += BLOCK) needbits[i] = 0u;
+            __syncthreads();
+            for (int w = tid; w < B; w += BLOCK) {
+                // (walkers outside the prior or already known to be -inf need no sums either: lf_finalize)
+                const int st_ = zc.wstat[w];
+                const bool wants = VARIANT == LF_FIXCOMP ? (st_ & STAT_SLOW) != 0 : !(st_ & STAT_CELLS);
+                if (wants && (st_ & STAT_PRIOR_OK) && !(st_ & STAT_NEGINF)) {
+                    atomicOr(&needbits[(w >> 5) & (ZCELL_MAXB / 32 - 1)], 1u << (w & 31));      // (B > ZCELL_MAXB: bits shared, only ever too many set)
+                    anyneed = 1;
+                }
+            }
+            __syncthreads();
+            if (!anyneed) return;
+            load_tables_256(&tab);
+            __syncthreads();
+            for (int sid = id - nblkB; sid < nsrc_wg; sid += zc.nwork) {
+                int c, w0, nw;
+                src_item(sid, c, w0, nw);
+                int need = 0;
+                for (int w = w0; w < w0 + nw; ++w) need |= (needbits[(w >> 5) & (ZCELL_MAXB / 32 - 1)] >> (w & 31)) & 1u;
+                if (!need) continue;                   // (uniform: LDS broadcast reads)
+                srcsum_body<VARIANT, ST, TW, CMP>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
+                __syncthreads();
+            }
+            return;
+        }
     }
     load_tables_256(&tab);
     __syncthreads();
-    if (ZC && id >= nblkB + nsrc_wg) {
-        const int k = id - (nblkB + nsrc_wg);           // cell workgroups: (chunk, tile of TW walkers)
+    if (ZC && zc.nchC > 0 && zc.nwork > 0 && id >= nblkB + zc.nwork) {
+        const int k = id - (nblkB + zc.nwork);          // cell workgroups: (chunk, tile of TW walkers)
         const int ntc = (B + TW - 1) / TW;
         const int cc = k / ntc, w0c = (k - cc * ntc) * TW;
         zcell_body<TW>(kc, zc, wrec, cc, w0c, min(TW, B - w0c), tab, red);
@@ -1365,17 +1402,7 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
         return;
     }
     int c, w0, nw;
-    if (id < nbig) {
-        const int wg = xcd_renumber(id, nbig);
-        c = wg / tl.ntiles;
-        w0 = (wg - c * tl.ntiles) * tl.tw;
-        nw = min(tl.tw, tl.B1 - w0);
-    } else {
-        const int wg = xcd_renumber(id - nbig, nchA * tl.ntiles_s);
-        c = wg / tl.ntiles_s;
-        w0 = tl.B1 + (wg - c * tl.ntiles_s) * tl.tws;
-        nw = min(tl.tws, B - w0);
-    }
+    src_item(id, c, w0, nw);
     srcsum_body<VARIANT, ST, TW, CMP>(kc, sa, wrec, wmode, c, w0, nw, partA, strideA, tab, red);
 }
 
@@ -1437,7 +1464,8 @@ __global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __r
 template <bool COHERENT>
 __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int strideA, const double* partB, int nchB, int strideB,
                                               const double* partR, int nchR, int alt_flag, const int* wstat, const double* wbase,
-                                              int w, int lane, const AcceptArgs& ap, double* out, double* outA, double* outB) {
+                                              int w, int lane, const AcceptArgs& ap, double* out, double* outA, double* outB,
+                                              int a_flag = 0) {
     auto ld = [](const double* p) -> double {
         if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return *p;
@@ -1450,6 +1478,8 @@ __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int
     const double* pa = resc ? partR + (size_t)w * nchR : partA + (size_t)w * strideA;
     const double* pb = partB + (size_t)w * strideB;
     if (resc) nchA = nchR;
+    // (a_flag: per-source partials were only made for walkers with this flag - fixed completeness, careful path)
+    else if (a_flag && !(st & a_flag)) nchA = 0;
     // four independent running sums per lane so that the loads are in flight together (latency kernel)
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int c = lane;
@@ -1485,12 +1515,12 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
                                                   const int* __restrict__ wstat,
                                                   const double* __restrict__ wbase, int B, AcceptArgs ap,
                                                   double* __restrict__ out, double* __restrict__ outA,
-                                                  double* __restrict__ outB, int* __restrict__ slow_list) {
+                                                  double* __restrict__ outB, int* __restrict__ slow_list, int a_flag) {
     const int w = blockIdx.x;
     if (w >= B) return;
     if (slow_list && w == 0 && threadIdx.x == 0) slow_list[0] = 0;     // lf_main has consumed the list
     finalize_wave<false>(partA, nchA, strideA, partB, nchB, strideB, partR, nchR, alt_flag, wstat, wbase, w, (int)threadIdx.x, ap, out,
-                         outA, outB);
+                         outA, outB, a_flag);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -484,10 +484,16 @@ void launch_geo(lf_ctx* c, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int n
                      GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, (int)CMP, nb, fa.numRegs, fa.sharedSizeBytes, grid.x);
     }
     ZCells zc{};
-    if (VARIANT == LF_ZEVOL && !CMP && c->zcells.nchC > 0) {
-        zc = c->zcells;                           // cell workgroups after the per-source ones: (chunk, tile of TW walkers)
-        grid.x += (unsigned)(zc.nchC * ((B + GEOS[GI].tw - 1) / GEOS[GI].tw));
-        c->last_launch[4] = (int)grid.x;
+    if (!CMP && ((VARIANT == LF_ZEVOL && c->zcells.nchC > 0) || VARIANT == LF_FIXCOMP)) {
+        zc = c->zcells;
+        // the per-source items are shared by a bounded number of workers (lf_kernels.h: lf_main), the cell workgroups come
+        // after them: (chunk, tile of TW walkers)
+        const int nsrc_wg = nchA * (tl.ntiles + tl.ntiles_s);
+        zc.nwork = std::min(nsrc_wg, 4 * std::max(c->num_cu, 1));
+        if (zc.nwork > 0) {
+            grid.x = (unsigned)(nblkB + zc.nwork + zc.nchC * ((B + GEOS[GI].tw - 1) / GEOS[GI].tw));
+            c->last_launch[4] = (int)grid.x;
+        }
     }
     hipLaunchKernelGGL((lf_main<VARIANT, GEOS[GI].st, GEOS[GI].tw, GEOS[GI].twb, CMP>), grid, dim3(BLOCK), 0, s, c->kc, sa,
                        na, c->d_wrec, c->d_wmode, B, tl, nchA, ntilesB, twb, nblkB, c->d_partA, nchA, c->d_partB, nchB, rs, gc, zc);
@@ -640,7 +646,7 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
         const int nB = nchB > 0 ? nslot : 0, nC = nchC > 0 ? nslot : 0;
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nB, nB,
                            nC > 0 ? (const double*)c->d_partR : (const double*)nullptr, nC, (int)STAT_CELLS, c->d_wstat, c->d_wbase, B, ap,
-                           d_out, d_outA, d_outB, (int*)nullptr);
+                           d_out, d_outA, d_outB, (int*)nullptr, 0);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;
@@ -704,7 +710,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     const int nchC = !cmp && c->kc.variant == LF_ZEVOL && c->kc.cells ? c->ncchunk : 0;
     rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * std::max(nchB, 1), (size_t)B * std::max(nchD, nchC));
     if (rc != LF_OK) return rc;
-    c->zcells = ZCells{c->d_cells, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat};
+    c->zcells = ZCells{c->d_cells, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat, 0};
     // the workspace is shared by consecutive calls: order a stream switch behind the previous work
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
@@ -790,7 +796,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         Prof p(c, s, 3);
         hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nchA, nchA, c->d_partB, nchB, nchB,
                            cmp || nchC > 0 ? c->d_partR : nullptr, cmp ? nchD : nchC, (int)(cmp ? STAT_SLOW : STAT_CELLS), c->d_wstat,
-                           c->d_wbase, B, ap, d_out, d_outA, d_outB, cmp ? c->d_slow : nullptr);
+                           c->d_wbase, B, ap, d_out, d_outA, d_outB, cmp ? c->d_slow : nullptr,
+                           !cmp && c->kc.variant == LF_FIXCOMP && nchA > 0 ? (int)STAT_SLOW : 0);
     }
     LF_HIP(c, hipGetLastError());
     return LF_OK;

@@ -382,11 +382,18 @@ def test_zevol_cells_equal_the_sum_over_sources(n, nf, zslices, pivots, rows):
     rng = np.random.default_rng(43)
     wild = np.arange(rows) % 4 == 3                         # every 4th walker anywhere in the box
     th[wild, 0:3] = rng.uniform(41.2, 44.8, (int(wild.sum()), 3))
+    # ... and a few with L* so low that the brightest sources' exp(-10^(lum - L*)) is near underflow: inside the prior,
+    # but on the careful path, i.e. summed over the SOURCES (by the workers that share the per-source items) while
+    # their tile-mates take the cells
+    low = np.arange(rows) % 16 == 5
+    th[low, 0:3] = float(np.max(inp["lum"])) - np.log10(716.0)          # (10^(lum_max - L*) = 716: careful from 700, -inf from 745)
     ref = O.lnprob_batch(inp, th[:6]) if n <= 400000 else None
     ctx = LFContext(inp)
     ctx.set_option("count_forms", 1)
     a1, b1 = ctx.lnprob_pieces(th)
-    ncell = ctx.form_counts()["cell"]
+    fc = ctx.form_counts()
+    ncell = fc["cell"]
+    assert fc["careful"] > 0, fc                                  # (some walkers were summed over the sources, term by term)
     ctx.set_option("count_forms", 0)
     lp1 = ctx.lnprob_batch(th)
     ctx.set_option("cells", 0)
@@ -423,6 +430,9 @@ def test_fixcomp_grid_summed_over_its_rows(sep, monkeypatch):
         inp["logL"] = np.stack([np.linspace(lo + 0.3 * k / S, synth.LH, S) for k in range(S)], axis=1)
     th = synth.walkers("fixcomp", 40, seed=72)
     th[3, 0] = 40.2
+    # a walker on the careful path (the brightest source's exp(-10^(lum - L*)) near underflow): the only kind whose piece A
+    # is summed over the sources in this variant - by the workers that share the per-source items; its tile-mates' are not
+    th[4, 0] = th[20, 0] = float(np.max(inp["lum"])) - np.log10(716.0)
     ctx = LFContext(inp)
     a1, b1 = ctx.lnprob_pieces(th)
     lp = ctx.lnprob_batch(th[:10])
