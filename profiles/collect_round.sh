@@ -21,6 +21,9 @@ python3 bench.py $b --nsrc 100000 > $out/bench_n1e5.json 2>/dev/null
 python3 bench.py $b --nsrc 100000 --walkers 1024 > $out/bench_n1e5_w1024.json 2>/dev/null
 python3 bench.py $b --nsrc 1000 --walkers 32 > $out/bench_n1e3.json 2>/dev/null
 python3 bench.py $b --variant zevol > $out/bench_zevol.json 2>/dev/null
+python3 bench.py $b --variant zevol --nsrc 800000 --walkers 512 > $out/bench_zevol_800000_w512.json 2>/dev/null   # BASELINE config 5's shape on one GPU
+python3 bench.py $b --walkers 128 > $out/bench_w128.json 2>/dev/null     # config 4's share of one GPU: 1024 walkers over 8
+python3 bench.py $b --walkers 64 > $out/bench_w64.json 2>/dev/null
 python3 bench.py $b --variant zevol --no-cells > $out/bench_zevol_nocells.json 2>/dev/null
 python3 bench.py $b --variant fixcomp > $out/bench_fixcomp.json 2>/dev/null
 python3 bench.py $b --no-fuse > $out/bench_nofuse.json 2>/dev/null
