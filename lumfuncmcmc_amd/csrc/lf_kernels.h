@@ -63,6 +63,7 @@ constexpr double CELL_RHO_G = 1.5e-2, CELL_RHO_H = 3.0e-3;
 // the majorant series exp(X1 t + X2 t^2)).  Records {z_c, S_0 .. S_6}: ZCELL_M = 6.  rho (KConst::zcell_rho) is chosen when the context is made, at most
 // ZCELL_RHO and small enough that EVERY walker inside the prior box of L1..L3 passes (lfmcmc.hip: zcell_rho_for_box).
 constexpr double ZCELL_RHO = 1.0e-3, ZCELL_X1 = 6.0e-3, ZCELL_X2 = 1.0e-5;
+constexpr int ZCOLS = 3;                  // redshift columns a chunk of the column-major z-evolving grid may touch
 constexpr int ZCELL_M = 6;
 constexpr int ZCELL_REC = ZCELL_M + 2;
 
@@ -89,6 +90,8 @@ struct KConst {
     int specialise;           // 1: chunk-level term specialisation (term_free_noexp); 0 for A/B runs
     int cells;                // FREE, ZEVOL: 1 = the catalogue's cells exist and lf_prepare may flag walkers STAT_CELLS
     int cc_fstart[MAXF + 1];  // FREE: cell chunks (64 cells) of field f are [cc_fstart[f], cc_fstart[f + 1])
+    int zgrid_cols;           // ZEVOL: 1 = the grid's nodes are stored column by column (node = k S + j) and S >= BLOCK / (ZCOLS - 1),
+                              // so that a chunk of BLOCK nodes touches at most ZCOLS redshift columns (gridsum_body)
     double zcell_rho;         // ZEVOL: half the largest width of a cell in redshift (ZCELL_RHO below)
     int kf_first[MAXF], kf_last[MAXF];   // FREE: keys (floor / ceil) of each field's faintest / brightest source
     int grid_part, grid_parts; // source-sharded ranks split piece B too: this context integrates the node chunks c with
@@ -1090,6 +1093,45 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
     const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0;
     const double a3 = na.a3[g], a4 = na.a4[g];
     const double a4min = VARIANT == LF_FREE ? na.a4min[c] : 0.0;      // wave-uniform
+    if (VARIANT == LF_ZEVOL && kc.zgrid_cols) {
+        // The z-evolving integrand at node (j, k) is W exp(c1 (G - L*(z_k)) + ln10 phi*(z_k) + ln ln10 - 10^(G - L*(z_k))),
+        // and everything of the walker in it depends on the COLUMN k only:
+        //     10^(G - L*(z_k)) = PG * Q_wk,   Q_wk = 10^(42 - L*(z_k));      the rest = c1 (G - 42) + E_wk.
+        // The nodes are stored column by column (lfmcmc.hip: build), so a chunk of 256 touches at most ZCOLS columns: a few
+        // lanes make Q and E of the tile's walkers for them (one exponential each), and a node costs ONE exponential and no
+        // parabola instead of two and two.
+        __shared__ double qe[TW * ZCOLS * 2];
+        const int S = kc.S, k0 = (c * BLOCK) / S;
+        if (tid < nw * ZCOLS) {
+            const int w = tid / ZCOLS, cc = tid - w * ZCOLS;
+            const int k = min(k0 + cc, S - 1);
+            const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
+            const double z = na.a3[(size_t)k * S], z2 = na.a4[(size_t)k * S];
+            const double Ls = quad_nofma(r[Z_AL], r[Z_BL], r[Z_CL], z, z2);        // lumfuncmcmc_z.py:66
+            const double ph = quad_nofma(r[Z_AP], r[Z_BP], r[Z_CP], z, z2);        // :65
+            qe[tid * 2] = fexp_c(LF_LN10 * (LF_LREF - Ls), &tab);
+            qe[tid * 2 + 1] = fma(-r[Z_C1], Ls - LF_LREF, fma(LF_LN10, ph, LF_LNLN10));
+        }
+        __syncthreads();
+        const int cc = min(gi, na.nnodes - 1) / S - k0;      // this node's column among the chunk's (threads past the end: the last)
+        const double Gm = G - LF_LREF;
+        if (kc.forms && tid == 0) atomicAdd(kc.forms + FORM_NODE_GENERAL, (unsigned long long)min(BLOCK, na.nnodes - c * BLOCK) * nw);
+#pragma unroll 1
+        for (int w = 0; w < nw; ++w) {
+            double val = 0.0;
+            if (wmode[(size_t)(w0 + w) * MAXF * WM] != MODE_SKIP) {      // (outside the prior: not evaluated)
+                const double c1 = uni(wrec[(size_t)(w0 + w) * REC + Z_C1]);
+                const double Q = qe[(w * ZCOLS + cc) * 2], E = qe[(w * ZCOLS + cc) * 2 + 1];
+                asm volatile("; LF_BEGIN znode items=1");
+                val = W * fexp_c(fma(c1, Gm, E) - PG * Q, &tab);
+                asm volatile("; LF_END znode");
+            }
+            red[w * BLOCK + tid] = val;
+        }
+        __syncthreads();
+        reduce_store(red, nw, partial, (size_t)pstride, w0, c);
+        return;
+    }
 #pragma unroll 1
     for (int w = 0; w < nw; ++w) {
         const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
@@ -1111,9 +1153,9 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
             const WZ wz{r[Z_AL], r[Z_BL], r[Z_CL], r[Z_AP], r[Z_BP], r[Z_CP], r[Z_C1], 0.0};
             double v;
             if (kc.forms && tid == 0) atomicAdd(kc.forms + FORM_NODE_GENERAL, (unsigned long long)min(BLOCK, na.nnodes - c * BLOCK));
-            asm volatile("; LF_BEGIN znode items=1");
+            asm volatile("; LF_BEGIN znode_rows items=1");
             val = W * fexp_c(lnT_zevol<true>(wz, G, a3, a4, v, &tab), &tab);
-            asm volatile("; LF_END znode");
+            asm volatile("; LF_END znode_rows");
         }
         red[w * BLOCK + tid] = val;
     }

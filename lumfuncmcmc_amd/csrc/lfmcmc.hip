@@ -1250,6 +1250,18 @@ int build(lf_ctx* c, const lf_desc* d) {
             }
         }
     }
+    kc.zgrid_cols = 0;
+    if (d->variant == LF_ZEVOL && S >= lf::BLOCK / (lf::ZCOLS - 1) && !std::getenv("LF_NO_ZGRID_COLS")) {
+        // z-evolving: store the lattice column by column (a sum does not care; lf_kernels.h: gridsum_body takes what depends
+        // on the walker per COLUMN).  S >= 128: a chunk of 256 nodes then touches at most 3 columns.
+        std::vector<double> t(nn);
+        for (std::vector<double>* arr : {&G, &PG, &W, &a3, &a4}) {
+            for (int j = 0; j < S; ++j)
+                for (int k = 0; k < S; ++k) t[(size_t)k * S + j] = (*arr)[(size_t)j * S + k];
+            arr->swap(t);
+        }
+        kc.zgrid_cols = 1;
+    }
     if (d->variant == LF_FIXCOMP && !std::getenv("LF_NO_COLLAPSE_GRID")) {        // (the variable: A/B runs and the test of this step)
         // Fixed completeness: the integrand at node (j, k) is T_w(L_jk) W_jk with everything but the Schechter function
         // T folded into W.  When every redshift column has the same luminosity nodes (the constructor clips the columns'

@@ -453,3 +453,30 @@ def test_fixcomp_grid_summed_over_its_rows(sep, monkeypatch):
     f = np.isfinite(ref)
     assert np.array_equal(f, np.isfinite(lp))
     np.testing.assert_allclose(lp[f], ref[f], rtol=RTOL)
+
+
+def test_zevol_grid_by_columns_equals_the_grid_by_nodes(monkeypatch):
+    """The z-evolving grid integral with the walker's factors taken per redshift COLUMN (nodes stored column by column,
+    one exponential per node) against the node-by-node form of the same build (LF_NO_ZGRID_COLS: two exponentials and two
+    parabolas per node) and the oracle; walkers over the whole prior box, one outside it."""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("zevol", 60000, seed=81, zslices=8)
+    th = synth.walkers("zevol", 37, seed=82)
+    th[2, 3] = 9.0
+    ctx = LFContext(inp)
+    a1, b1 = ctx.lnprob_pieces(th)
+    lp1 = ctx.lnprob_batch(th)
+    ctx.close()
+    monkeypatch.setenv("LF_NO_ZGRID_COLS", "1")
+    ctx = LFContext(inp)
+    a0, b0 = ctx.lnprob_pieces(th)
+    ctx.close()
+    fin = np.isfinite(b0)
+    assert fin.sum() >= 30 and np.array_equal(fin, np.isfinite(b1))
+    np.testing.assert_array_equal(a1[fin], a0[fin])
+    np.testing.assert_allclose(b1[fin], b0[fin], rtol=2e-14)
+    assert not np.array_equal(b1[fin], b0[fin])              # (it is another route to the same numbers)
+    ref = O.lnprob_batch(inp, th[:10])
+    f = np.isfinite(ref)
+    assert np.array_equal(f, np.isfinite(lp1[:10]))
+    np.testing.assert_allclose(lp1[:10][f], ref[f], rtol=RTOL)
