@@ -410,7 +410,11 @@ def roofline_of(args, leg, model, kt, dt):
             "valu_issue_frac_at_2p4GHz": (src_cycles + grid_cycles) / 64.0 / (avg_ms * 1e-3) / (1024 * 2.4e9),
             "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
-            "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items() if n != "unused"}}
+            "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items() if n != "unused"},
+            "note": ("frac prices EXECUTED fp64 flops (census x ISA counts) against the vector-fp64 peak. Walkers summed over the "
+                     "catalogue's cells execute ~11x fewer flops per launch than the per-source kernel (--no-cells: frac 0.43) in "
+                     "~4x less time, so frac falls while evals/s rises; the launch is ~0.6 VALU-busy over its whole length "
+                     "(profiles/*_pmc.json), the rest is dispatch, table load, walker preparation and the final sums") if cnt.get("cell", 0.0) > 0.0 else None}
 
 
 def main():
