@@ -89,7 +89,12 @@ int lf_abi_version(void);
 
 /* Replaces the read side of LumFuncMCMC.__init__ / LumFuncMCMCz.__init__ (lumfuncmcmc.py:162-177):
  * copies the catalogue and grids to HBM, derives the parameter-independent per-source and
- * per-node tables.  Returns NULL on failure; lf_last_error(NULL) then holds the reason. */
+ * per-node tables.  Returns NULL on failure; lf_last_error(NULL) then holds the reason.
+ * What is derived here, beyond the reference's arrays: the catalogue's cells (option "cells" of lf_set_option); for
+ * fixed completeness the integration grid summed over its rows when every redshift column has the same luminosity
+ * nodes; for the z-evolving model the grid stored column by column.  Two environment variables, read here, switch
+ * the last two off for A/B tests - LF_NO_COLLAPSE_GRID, LF_NO_ZGRID_COLS (results agree to rounding either way);
+ * LF_DEBUG_OCC prints the occupancy of a kernel instantiation at its first launch. */
 lf_ctx *lf_create(const lf_desc *desc);
 
 /* Releases device and host memory of the context. */
