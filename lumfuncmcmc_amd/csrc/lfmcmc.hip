@@ -1851,11 +1851,26 @@ int lf_sampler_read(lf_sampler* sm, double* chain, double* chain_lnprob, int64_t
     LF_HIP(c, hipDeviceSynchronize());
     const size_t W = (size_t)sm->W, nd = (size_t)sm->ndim, cap = (size_t)sm->cap, t = (size_t)sm->t;
     // device chain is [W][cap][ndim]; the caller's is [W][t][ndim]: one strided copy each
-    if (t > 0) {
-        if (chain)
-            LF_HIP(c, hipMemcpy2D(chain, t * nd * 8, sm->d_chain, cap * nd * 8, t * nd * 8, W, hipMemcpyDeviceToHost));
-        if (chain_lnprob)
-            LF_HIP(c, hipMemcpy2D(chain_lnprob, t * 8, sm->d_chain_lnp, cap * 8, t * 8, W, hipMemcpyDeviceToHost));
+    // (packed on the device first, then ONE copy to the host: a strided copy into pageable host memory goes row by row)
+    if (t > 0 && (chain || chain_lnprob)) {
+        double* tmp = nullptr;
+        LF_HIP(c, hipMalloc((void**)&tmp, W * t * nd * 8));
+        int rc = LF_OK;
+        if (chain) {
+            if (hipMemcpy2D(tmp, t * nd * 8, sm->d_chain, cap * nd * 8, t * nd * 8, W, hipMemcpyDeviceToDevice) != hipSuccess ||
+                hipMemcpy(chain, tmp, W * t * nd * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = LF_ERR_HIP;
+        }
+        if (rc == LF_OK && chain_lnprob) {
+            if (hipMemcpy2D(tmp, t * 8, sm->d_chain_lnp, cap * 8, t * 8, W, hipMemcpyDeviceToDevice) != hipSuccess ||
+                hipMemcpy(chain_lnprob, tmp, W * t * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = LF_ERR_HIP;
+        }
+        hipFree(tmp);
+        if (rc != LF_OK) {
+            c->err = "lf_sampler_read: copy failed";
+            return rc;
+        }
     }
     if (naccepted) LF_HIP(c, hipMemcpy(naccepted, sm->d_nacc, W * sizeof(long long), hipMemcpyDeviceToHost));
     if (pos) LF_HIP(c, hipMemcpy(pos, sm->d_pos, W * nd * 8, hipMemcpyDeviceToHost));

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--nsrc", type=int, default=1000000)
     ap.add_argument("--walkers", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--opts", default="", help="context options for the timed part, k=v,k=v")
     ap.add_argument("--ball", type=float, default=0.0, help="start in a ball of this relative size around the box centre instead of box-uniform")
     a = ap.parse_args()
     model = bench.build_model("free", a.nsrc, a.walkers, 0)
@@ -39,13 +40,21 @@ def main():
     print("(walker, source) terms per half-step if every proposal were summed over the sources: %d" % (rows * a.nsrc))
     import time
     import torch
+    for kv in filter(None, a.opts.split(",")):
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ds.run_mcmc(None, a.steps)
+        ds.enqueue(None, a.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print("%.1f us per half-step; acceptance %.3f" % (1e6 * dt / calls, float(np.mean(ds.acceptance_fraction))))
+        ds.sync()
+        t_read = time.perf_counter() - t0 - dt
+    print("read-back of the chain so far (%d steps): %.2f ms" % (ds.iterations, 1e3 * t_read))
+    ll = ctx.last_launch()
+    print("%.1f us per half-step (%s%s); acceptance %.3f" % (1e6 * dt / calls, ll["kernel"], ", one launch" if ll["fused"] else "",
+                                                          float(np.mean(ds.acceptance_fraction))))
 
 
 if __name__ == "__main__":
