@@ -183,7 +183,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             if (u < 64)
                 prepare_lane<false>(kc, StepArgs{}, fa.theta, fa.B, fa.wrec_w, fa.wstat_w, fa.wmode_w, fa.wbase_w, nullptr, 1,
                                     w0 + (u >> 3), u & 7, u >> 3, reinterpret_cast<double(*)[16]>(red));
-            __threadfence_block();                // the records are read back from memory below, by every wave of this workgroup
+            // the records are read back from memory below, by every wave of this workgroup: the wave that wrote them waits
+            // for its stores' acknowledgements first (a workgroup-scope fence alone does not make the compiler emit that wait)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __threadfence_block();
             __syncthreads();
         }
         if (u < 64) {
@@ -516,9 +519,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         }
         if (FUSED) {
             // This workgroup's partial sums are out - written through, and complete once its waves have waited for their
-            // stores, which the fence makes them do before the barrier; the count (an atomic of agent scope, done at the
-            // memory side) comes after the barrier.  The last of the tile's workgroups to count adds the partials up,
+            // stores' acknowledgements (the explicit s_waitcnt: the compiler does not emit one for a workgroup-scope fence,
+            // and the count must not overtake a partial sum on its way to memory); the count (an atomic of agent scope)
+            // comes after the barrier.  The last of the tile's workgroups to count adds the partials up,
             // reading them from memory (finalize_wave<true>); the walkers' records it needs are its own copies.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (every wave: its write-through stores have been acknowledged)
             __threadfence_block();
             __syncthreads();
             if (fresh_tid() == 0) sitem[1] = atomicAdd(q, 1);
