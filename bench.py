@@ -447,7 +447,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
-    ap.add_argument("--profile-every", type=int, default=4,
+    ap.add_argument("--profile-every", type=int, default=8,
                     help="bracket only every n-th evaluation of the timed steps with events (each pair stalls the stream ~8 us)")
     args = ap.parse_args()
     if args.gpus < 1:
