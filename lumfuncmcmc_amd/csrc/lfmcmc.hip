@@ -493,7 +493,9 @@ void launch_geo(lf_ctx* c, dim3 grid, lf::Tiling tl, int ntilesB, int twb, int n
         // the per-source items are shared by a bounded number of workers (lf_kernels.h: lf_main), the cell workgroups come
         // after them: (chunk, tile of TW walkers)
         const int nsrc_wg = nchA * (tl.ntiles + tl.ntiles_s);
-        zc.nwork = std::min(nsrc_wg, 4 * std::max(c->num_cu, 1));
+        // (one per CU: idle workers still cost ~0.6 us per 256 of them - 20.7 / 19.8 / 18.9 us with 4 / 2 / 1 per CU at 128
+        // rows - and the rare walker that needs the sources has 490 items for 256 workers)
+        zc.nwork = std::min(nsrc_wg, std::max(c->num_cu, 1));
         if (zc.nwork > 0) {
             grid.x = (unsigned)(nblkB + zc.nwork + zc.nchC * ((B + GEOS[GI].tw - 1) / GEOS[GI].tw));
             c->last_launch[4] = (int)grid.x;
