@@ -167,6 +167,16 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * "fuse": 1 (default) lets lf_free do lf_prepare's and lf_finalize's work itself for plain evaluations - one launch
  * instead of three, same bits; 0 = three launches (A/B runs; the sampler's steps, lf_lnprob_pieces, the census and
  * profiling level 2 always take three).  "profile_every": see lf_set_profiling.
+ * "grid_shortcut": 1 (default) lets lf_free take piece B of a FREE context whose integration grid is separable (every
+ * redshift column has the same luminosity nodes: min_comp_frac = 0) over FLUX BINS instead of the S^2 lattice points: the
+ * completeness depends on a lattice point only through its log flux L_j - D_k, so per bin the lattice points of a row are
+ * replaced by the bin's 64 Chebyshev nodes with weights from the row's moments (exact for polynomials of degree < 64),
+ * and the Schechter factor of the rows enters by a dot product.  The bins are made at lf_create such that the
+ * interpolation error of the completeness curve is PROVEN (Bernstein-ellipse bound, evaluated for the whole prior box
+ * of alpha_C and Flim - csrc/lf_gridbound.h, tests/test_gridbound_cpu.py) to be below 1e-15 of the curve's smallest
+ * value in the bin + 1e-30: |piece B (bins) - piece B (lattice)| <= 1e-15 piece B + 1e-30 x (piece B at completeness 1).
+ * 16-20 bins x 64 nodes per field instead of 10 201 lattice points.  No proven set of bins (a prior box that reaches
+ * alpha_C <= 0, a grid that is not separable) = the lattice; 0 = the lattice (A/B runs).
  * "specialise": 1 (default) lets the free variant take the cheaper form of the term for (walker, chunk) pairs whose
  * every source has f / f_tau > 37.5 (decay factor exactly 1.0 in binary64); 0 = always the general form (A/B runs).
  * Two keys change what is computed, for SOURCE-SHARDED ranks whose lnprob values are summed (all-reduce): "skip_grid" = 1
@@ -240,6 +250,15 @@ int64_t lf_compress_keys(int kind, const double *params, const double *key, cons
 int64_t lf_compress_grid(const double *params, int S, const double *L, const double *wL, const double *ck,
                          const double *Dk, double *u, int32_t *row0, int32_t *nrows, int32_t *off, double *omega,
                          int64_t cap_bins, int64_t cap_omega, double *bound);
+
+/* Host-only helper behind "grid_shortcut", exported for tests (touches no GPU).  Arguments as lf_compress_grid.  Outputs
+ * per bin: edges[2], rec[64][4] = {node x_n, 10^(x_n + 17), L of row row0 + n (the last row again past the bin's rows),
+ * 10^(that - 42)}, rows[4] = {row0, nrows, offset into omega, 0}, omega [row][64].  *margin = ln(proven error bound /
+ * allowance) of the worst bin, <= 0.  Returns the number of bins (outputs written when the capacities suffice),
+ * or a negative code when no proven set of bins exists. */
+int64_t lf_grid_bins(const double *params, int S, const double *L, const double *wL, const double *ck, const double *Dk,
+                     double *edges, double *rec, int32_t *rows, double *omega, int64_t cap_bins, int64_t cap_omega,
+                     double *margin);
 
 /* 1/Veff estimator on the device (post-fit diagnostic, no context needed).  Replaces the per-source loop of
  * LumFuncMCMC.VeffLF (lumfuncmcmc.py:515-525: V.lumfunc, one scipy.quad per source, VmaxLumFunc.py:235-257) and the

@@ -43,7 +43,7 @@ EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_ba
            "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
-           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_form_counts", "lf_last_launch", "lf_veff")
+           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_grid_bins", "lf_form_counts", "lf_last_launch", "lf_veff")
 
 _lib = None
 
@@ -169,6 +169,33 @@ def compress_grid(params, L, wL, ck, Dk):
     nom = int(off[nb - 1] + nrows[nb - 1] * 16)
     return {"u": u[:nb * 16].reshape(nb, 16).copy(), "row0": row0[:nb].copy(), "nrows": nrows[:nb].copy(),
             "off": off[:nb].copy(), "omega": omega[:nom].copy(), "bound": float(bound[0])}
+
+
+def grid_bins(params, L, wL, ck, Dk):
+    """Host-only helper behind piece B over flux bins (csrc/lf_gridbound.h: build_gridq; the default of FREE contexts with
+    a separable grid).  params = |a/(1-a)|, alpha_lo, alpha_hi, flim_lo, flim_hi.  Returns a dict with edges (nb, 2), rec
+    (nb, 64, 4) = {x_n, 10^(x_n + 17), L of row row0 + n, 10^(that - 42)}, rows (nb, 4) = {row0, nrows, offset, 0}, omega
+    (flat, per bin [row][64]) and margin = ln(proven bound / allowance) <= 0.  Touches no GPU."""
+    lib = load()
+    params, L, wL, ck, Dk = (_f64(a) for a in (params, L, wL, ck, Dk))
+    S = L.size
+    capb, capo = 1024, 1024 * 64 * 64
+    edges, rec = np.empty(capb * 2), np.empty(capb * 64 * 4)
+    rows = np.empty(capb * 4, dtype=np.int32)
+    omega = np.empty(capo)
+    margin = np.zeros(1)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lib.lf_grid_bins.restype = ctypes.c_int64
+    lib.lf_grid_bins.argtypes = [_c_double_p, ctypes.c_int] + [_c_double_p] * 6 + [ip, _c_double_p, ctypes.c_int64, ctypes.c_int64,
+                                                                                   _c_double_p]
+    nb = lib.lf_grid_bins(_ptr(params), S, _ptr(L), _ptr(wL), _ptr(ck), _ptr(Dk), _ptr(edges), _ptr(rec), rows.ctypes.data_as(ip),
+                          _ptr(omega), capb, capo, _ptr(margin))
+    if nb < 0:
+        raise RuntimeError("lf_grid_bins failed (%d): no proven set of bins for this box" % nb)
+    rows = rows[:nb * 4].reshape(nb, 4).copy()
+    nom = int(rows[-1, 2] + rows[-1, 1] * 64)
+    return {"edges": edges[:nb * 2].reshape(nb, 2).copy(), "rec": rec[:nb * 256].reshape(nb, 64, 4).copy(), "rows": rows,
+            "omega": omega[:nom].copy(), "margin": float(margin[0])}
 
 
 def veff_device(flux, flim, vol, pref0, alpha, fcmin, bin_of=None, nbin=0, nboot=0, boot_idx=None, seed=0, device=0):

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "lf_compress.h"
+#include "lf_gridbound.h"
 #include "lf_kernels.h"
 #include "lf_free.h"
 
@@ -96,6 +97,15 @@ struct lf_ctx {
         double *d_U = nullptr, *d_A4 = nullptr, *d_omega = nullptr, *d_L = nullptr, *d_PGL = nullptr;
         int *d_row0 = nullptr, *d_nrows = nullptr, *d_off = nullptr;
     } gridc;
+    // FREE, separable grid: piece B over flux bins with a proven bound (lf_gridbound.h); lf_free's default when built
+    struct {
+        bool built = false;
+        int nb = 0;
+        double margin = 0.0;
+        double *d_rec = nullptr, *d_omega = nullptr;
+        int* d_rows = nullptr;
+    } gridq;
+    int64_t opt_grid_shortcut = 1;      // 0: lf_free integrates the lattice (A/B runs)
     double* d_partR = nullptr;          // rescue partials [B][chunks of the real catalogue]
     int* d_slow = nullptr;              // {count, walker indices...} of the walkers lf_prepare flagged SLOW (compressed mode)
     int cap_slow = 0;
@@ -598,7 +608,8 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     int rc = get_chunks(c, c->chunks_free, c->field_ind, PB * st, &ct, c->h_x.data(), st);
     if (rc != LF_OK) return rc;
     const int nchA = ct->n;
-    const int nchB = c->opt_skip_grid ? 0 : (c->nnodes + 63) / 64;        // chunks of 64 nodes: a wave's lanes
+    const bool gq = c->gridq.built && c->opt_grid_shortcut && !c->opt_skip_grid;      // piece B over flux bins (one bin per chunk)
+    const int nchB = c->opt_skip_grid ? 0 : (gq ? c->gridq.nb : (c->nnodes + 63) / 64);        // chunks of 64 nodes: a wave's lanes
     const int nchC = c->kc.cells ? c->ncchunk : 0;
     const int g8 = st == 8 ? free_groups<8>(c, slot, ntiles, nchA, nchB, nchC)
                  : st == 4 ? free_groups<4>(c, slot, ntiles, nchA, nchB, nchC) : free_groups<2>(c, slot, ntiles, nchA, nchB, nchC);
@@ -638,7 +649,8 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
     FreeArgs fa{B, ntiles, nchA, nchB, nslot, g8, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
                 c->d_cells, c->d_nodes8, c->d_cc_start, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat,
-                d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat, c->d_wbase};
+                d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat, c->d_wbase,
+                gq ? c->gridq.d_rec : nullptr, gq ? c->gridq.d_omega : nullptr, gq ? c->gridq.d_rows : nullptr, gq ? c->gridq.nb : 0};
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
@@ -1023,6 +1035,9 @@ void free_ctx(lf_ctx* c) {
         int* gi_[] = {g.d_row0, g.d_nrows, g.d_off};
         for (int* b : gi_)
             if (b) hipFree(b);
+        if (c->gridq.d_rec) hipFree(c->gridq.d_rec);
+        if (c->gridq.d_omega) hipFree(c->gridq.d_omega);
+        if (c->gridq.d_rows) hipFree(c->gridq.d_rows);
     }
     double* bufs[] = {c->d_lum, c->d_a1, c->d_P, c->d_U, c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->d_nodes8,
                       c->d_theta, c->d_out, c->d_outA, c->d_outB, c->d_wrec, c->d_partA, c->d_partB};
@@ -1253,6 +1268,23 @@ int build(lf_ctx* c, const lf_desc* d) {
                 const double dlcm = LF_MPC_CM * d->dl_zarr[k];
                 c->h_Dk[k] = std::log10(4.0 * M_PI * dlcm * dlcm);
                 c->h_ck[k] = wz[k] * d->volume_part[k];
+            }
+            // piece B over flux bins (lf_gridbound.h): the bins are proven for the context's whole prior box of (alpha_C, Flim),
+            // or the lattice stays.  Every rank of a sharded run derives the same bins from the same grid and box.
+            const double alo = kc.lims[LF_LIM_ALPHA][0], ahi = kc.lims[LF_LIM_ALPHA][1];
+            const double flo = kc.lims[LF_LIM_FLIM][0], fhi = kc.lims[LF_LIM_FLIM][1];
+            if (alo > 0.0 && ahi >= alo && flo > 0.0 && fhi >= flo && std::isfinite(ahi) && std::isfinite(fhi) && !std::getenv("LF_NO_GRIDQ")) {
+                const lfq::Box bx{std::sqrt(kc.fc_ratio), alo, ahi, std::log10(flo) + LF_FREF, std::log10(fhi) + LF_FREF};
+                lfq::GridQ gq;
+                if (lfq::build_gridq(bx, S, c->h_L.data(), c->h_wL.data(), c->h_ck.data(), c->h_Dk.data(), LF_FREF, LF_LREF, gq)) {
+                    auto& g = c->gridq;
+                    if ((rc = upload(c, &g.d_rec, gq.rec.data(), gq.rec.size())) != LF_OK) return rc;
+                    if ((rc = upload(c, &g.d_omega, gq.omega.data(), gq.omega.size())) != LF_OK) return rc;
+                    if ((rc = upload(c, &g.d_rows, gq.rows.data(), gq.rows.size())) != LF_OK) return rc;
+                    g.nb = gq.nb;
+                    g.margin = gq.margin;
+                    g.built = true;
+                }
             }
         }
     }
@@ -1665,6 +1697,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
         c->kc.specialise = value != 0;
         return LF_OK;
     }
+    if (std::strcmp(key, "grid_shortcut") == 0) {
+        c->opt_grid_shortcut = value != 0;
+        return LF_OK;
+    }
     if (std::strcmp(key, "compress_grid") == 0) {
         c->opt_compress_grid = value != 0;
         return LF_OK;
@@ -1742,6 +1778,22 @@ int64_t lf_compress_grid(const double* params, int S, const double* L, const dou
     std::copy(g.row0.begin(), g.row0.end(), row0);
     std::copy(g.nrows.begin(), g.nrows.end(), nrows);
     std::copy(g.off.begin(), g.off.end(), off);
+    std::copy(g.omega.begin(), g.omega.end(), omega);
+    return g.nb;
+}
+
+int64_t lf_grid_bins(const double* params, int S, const double* L, const double* wL, const double* ck, const double* Dk,
+                     double* edges, double* rec, int32_t* rows, double* omega, int64_t cap_bins, int64_t cap_omega, double* margin) {
+    if (!params || !L || !wL || !ck || !Dk || S < 2) return LF_ERR_ARG;
+    if (!(params[1] > 0.0) || !(params[3] > 0.0)) return LF_ERR_ARG;
+    const lfq::Box bx{std::sqrt(params[0]), params[1], params[2], std::log10(params[3]) + LF_FREF, std::log10(params[4]) + LF_FREF};
+    lfq::GridQ g;
+    if (!lfq::build_gridq(bx, S, L, wL, ck, Dk, LF_FREF, LF_LREF, g)) return LF_ERR_ARG;
+    if (margin) *margin = g.margin;
+    if (g.nb > cap_bins || (int64_t)g.omega.size() > cap_omega || !edges || !rec || !rows || !omega) return g.nb;
+    std::copy(g.edges.begin(), g.edges.end(), edges);
+    std::copy(g.rec.begin(), g.rec.end(), rec);
+    std::copy(g.rows.begin(), g.rows.end(), rows);
     std::copy(g.omega.begin(), g.omega.end(), omega);
     return g.nb;
 }
