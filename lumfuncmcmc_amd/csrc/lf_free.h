@@ -90,6 +90,7 @@ struct FreeArgs {
 template <int ST, bool CENSUS, bool FUSED = false>
 __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeArrays na, const double* __restrict__ wrec_arg,
                                                  const int* __restrict__ wmode_arg, FreeArgs fa) {
+    warm_kernarg<sizeof(KConst) + sizeof(SrcArrays) + sizeof(NodeArrays) + 2 * 8 + sizeof(FreeArgs)>();      // (lf_math.h: one round trip)
     const double* wrec = FUSED ? fa.wrec_w : wrec_arg;
     const int* wmode = FUSED ? fa.wmode_w : wmode_arg;
     // A partial sum: in the fused form it is read by a workgroup on another XCD while the launch is still running, so it
@@ -107,12 +108,19 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
     __shared__ int sitem[2];
     __shared__ int scell;                  // bit w: walker w of the tile is summed over the cells
     const int tid = threadIdx.x;
-    // ---- once per workgroup: the tables, and which XCD we are on
-    for (int i = tid; i < 256; i += PB) {
-        tab.logt[i] = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * i);
-        tab.expt[i] = EXP_TABLE[i];
+    __shared__ int sstat[PTW];             // FUSED: the tile's status words, straight from the preparation
+    __shared__ double sbase[PTW];          //        ... the closed-form part of piece A
+    __shared__ double wlf[PTW * MAXF];     //        ... lF per (walker, field) (the careful path's)
+    // ---- once per workgroup: the tables, and which XCD we are on.  (FUSED: waves 1..7 load them while wave 0 prepares the
+    // first tile's walkers - see the top of the tile loop.)
+    if (!FUSED) {
+        for (int i = tid; i < 256; i += PB) {
+            tab.logt[i] = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * i);
+            tab.expt[i] = EXP_TABLE[i];
+        }
+        load_term_tables<PB>(&tt);
     }
-    load_term_tables<PB>(&tt);
+    bool tables_loaded = !FUSED;
     // The thread number, made anew wherever it is needed (wave index from a scalar register, lane from mbcnt on an opaque
     // mask): what is derived from it - indices, addresses - is then computed where it is used.  Carried across the item
     // loop such values were spilled - 30 MB of scratch stores per launch from the prologue alone - and a reload from
@@ -135,6 +143,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
     }
     int nitems_done = 0;
     unsigned long long t_first = 0, t_sw = 0, t_loop = 0, t_red = 0;
+    unsigned long long t_prep = 0, t_cells = 0, t_grid = 0;      // (the last tile's: after the records are in LDS, the cells, the grid)
+    unsigned long long t_p0 = 0;                                 // wave 0 back from the preparation
+    __shared__ unsigned long long s_ttab;                        // wave 1 done with its share of the tables
+    __shared__ unsigned long long s_tprep[8];                    // inside the preparation: entry, theta in LDS, Q made, keys made, before the combine
 #endif
 
 #pragma unroll 1
@@ -185,19 +197,44 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
         const int u = fresh_tid();
         if (FUSED) {
-            if (u < 64)
-                prepare_lane<false>(kc, StepArgs{}, fa.theta, fa.B, fa.wrec_w, fa.wstat_w, fa.wmode_w, fa.wbase_w, nullptr, 1,
-                                    w0 + (u >> 3), u & 7, u >> 3, reinterpret_cast<double(*)[16]>(red));
-            // the records are read back from memory below, by every wave of this workgroup: the wave that wrote them waits
-            // for its stores' acknowledgements first (a workgroup-scope fence alone does not make the compiler emit that wait)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __threadfence_block();
+            // Wave 0 prepares the tile's 8 walkers (lf_prepare's body) and puts their records straight into LDS (wfc, wsc,
+            // wlf, sstat, sbase: the one-launch form writes no records to memory - the launch that makes them is the only
+            // one that reads them); the other seven waves meanwhile bring the tables in (first tile only).  Nobody waits for a trip through memory:
+            // the preparation's dependent chain (theta from memory, device-library exp10 / log10 / sqrt / log) and the
+            // tables' one round trip to L2 overlap, one barrier ends both.  (Records written to memory, acknowledged, read
+            // back by every wave, behind the tables' load: 8.0 of the launch's 19 us, tools/stamps_fused.py.)
+            if (u < 64) {
+                prepare_lane<false, true>(kc, StepArgs{}, fa.theta, fa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
+                                          w0 + (u >> 3), u & 7, u >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, wlf
+#ifdef LF_STAMPS
+                                          , s_tprep
+#endif
+                                          );
+#ifdef LF_STAMPS
+                t_p0 = __builtin_amdgcn_s_memtime();
+#endif
+            } else if (!tables_loaded) {
+                const int t7 = u - 64;            // 0 .. 447
+                // (all of a thread's loads in flight together: one round trip to the cold L2)
+                double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * min(t7, 255));
+                double et = EXP_TABLE[min(t7, 255)];
+                asm volatile("" : "+v"(lt.x), "+v"(lt.y), "+v"(et));
+                load_term_tables<PB - 64>(&tt, t7);
+                if (t7 < 256) {
+                    tab.logt[t7] = lt;
+                    tab.expt[t7] = et;
+                }
+#ifdef LF_STAMPS
+                if (t7 == 0) s_ttab = __builtin_amdgcn_s_memtime();
+#endif
+            }
+            tables_loaded = true;
             __syncthreads();
         }
         if (u < 64) {
             // which walkers of the tile lf_prepare put on the cells (one load per lane); when all of them are, the sources
             // are not touched
-            const int st = (FUSED ? fa.wstat_w : fa.wstat)[w0 + min(u, nw - 1)];
+            const int st = FUSED ? sstat[min(u, nw - 1)] : fa.wstat[w0 + min(u, nw - 1)];
             const bool on = fa.nchC > 0 && u < nw && (st & STAT_CELLS);
             // ... and which need the sources at all: not the ones outside the prior or already known to be -inf (their
             // lnprob is -inf whatever the sums are: lf_finalize).  A stretch-move ensemble puts such a proposal into nearly
@@ -211,8 +248,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 sitem[0] = grab();
             }
         }
-        // the tile's walker constants, all fields (64 B per (walker, field)), once
-        if (u < nw * MAXF) {
+        // the tile's walker constants, all fields (64 B per (walker, field)), once  (FUSED: they are in LDS already)
+        if (!FUSED && u < nw * MAXF) {
             const int w = u / MAXF, f = u - w * MAXF;
             double* d = wfc + u * 8;
             int* di = reinterpret_cast<int*>(d + 4);
@@ -230,11 +267,14 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 for (int i = 0; i < 5; ++i) di[i] = km[i];
             }
         }
-        if (u >= PB - PTW * 8) {                // (the last 64 threads: walker w, scalar slot j)
+        if (!FUSED && u >= PB - PTW * 8) {      // (the last 64 threads: walker w, scalar slot j)
             const int t = u - (PB - PTW * 8), w = t >> 3, j = t & 7;
             if (w < nw) wsc[t] = wrec[(size_t)(w0 + w) * REC + j];
         }
         __syncthreads();
+#ifdef LF_STAMPS
+        t_prep = __builtin_amdgcn_s_memtime();
+#endif
         const int cellmask = __builtin_amdgcn_readfirstlane(scell);
         // (No register prefetch of the next item: it would cost 16 VGPRs across the whole walker loop, and with 128 per
         // wave that means scratch traffic inside the loop - measured 4x slower.  The other workgroup of the CU computes
@@ -244,6 +284,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             const double2 a = p[0], b = p[1], c = p[3];
             // mode and keys: scalar loads straight from lf_prepare's table (wave-uniform address; five readfirstlanes
             // per walker fewer than through the LDS copy)
+            if (FUSED) {                            // (the keys are in the LDS copy; nothing of the records is read from memory)
+                const int* __restrict__ ki = reinterpret_cast<const int*>(wfc + (w * MAXF + fld) * 8 + 4);
+                return WalkerK{a.x, b.x, b.y, c.y, uni(ki[M_MODE]), uni(ki[M_KLO]), uni(ki[M_KHI]), uni(ki[M_KNE]), uni(ki[M_KAC])};
+            }
             const int* __restrict__ km = wmode + ((size_t)(w0 + w) * MAXF + fld) * WM;
             return WalkerK{a.x, b.x, b.y, c.y, km[M_MODE], km[M_KLO], km[M_KHI], km[M_KNE], km[M_KAC]};
         };
@@ -256,7 +300,13 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             // A wave adds up its lanes' values over ALL its chunks and reduces them once: one partial per (walker, workgroup)
             // (the chunks are dealt statically, so the order of the sums is fixed by the launch geometry).
             double acc = 0.0;
-            if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && frank < fa.nchC) {       // (wave-uniform)
+            // Who gets which chunk.  The workgroups of ranks >= fgroup / 2 are the YOUNGER ones of their CUs (the launch fills one
+            // slot of every CU before the second) and run ~2 us behind their elders in every phase (tools/stamps_fused.py), and
+            // a bin of the grid costs three cell chunks: so the bins go to the elders (rank c mod fgroup, from 0 up) and the
+            // cell chunks are dealt from the middle (chunk cc to rank (cc + fgroup / 2) mod fgroup): the younger half gets cells
+            // first and no bins.  Fixed by the launch geometry alone - not by which walkers are on the cells.
+            const int cfirst = (frank - fgroup / 2 + fgroup) % fgroup;
+            if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && cfirst < fa.nchC) {       // (wave-uniform)
                 // (Nothing but these loads goes through the vector memory counter inside the loop - chunk cc starts at cell
                 // 64 cc, its field comes from KConst by scalar compares, pads need no masking - so the next chunk's cells
                 // really are in flight while the current chunk is summed.  With the chunk table read from memory and the
@@ -279,9 +329,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     return f;
                 };
                 double nx[CELL_REC];
-                load_cells(nx, frank);
+                load_cells(nx, cfirst);
 #pragma unroll 1
-                for (int cc = frank; cc < fa.nchC; cc += fgroup) {
+                for (int cc = cfirst; cc < fa.nchC; cc += fgroup) {
                     double cd[CELL_REC];
 #pragma unroll
                     for (int k = 0; k < CELL_REC; ++k) cd[k] = nx[k];
@@ -302,6 +352,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     for (int i = fgroup + ln; i < fa.nslot; i += 64) pstore(row + i, 0.0);       // (slots of workgroups this tile does not have)
             }
         }
+#ifdef LF_STAMPS
+        t_cells = __builtin_amdgcn_s_memtime();
+#endif
         // ---- the grid integral (piece B).  Separable grid (the default): over FLUX BINS (lf_gridbound.h) - one bin of 64
         // Chebyshev nodes per wave-chunk, lane = node: the completeness sum over the fields at the node, times the dot product
         // of the Schechter function at the rows that cross the bin (one row per lane, handed round through LDS) with the
@@ -311,8 +364,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             const int v = wave_base >> 6;
             const int nq = fa.nbq;
             double bsum = 0.0;
-            int first = (frank - fa.nchC % fgroup) % fgroup;
-            first += first < 0 ? fgroup : 0;
+            // (bin c goes to the workgroup of rank c mod fgroup: see the cells' deal above)
+            const int first = frank;
             if (v < nw && first < nq) {
                 const double* __restrict__ sc = wsc + v * 8;
                 const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (v * MAXF) * 8 + 4));
@@ -435,6 +488,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     for (int i = fgroup + ln; i < fa.nslot; i += 64) pstore(row + i, 0.0);
             }
         }
+#ifdef LF_STAMPS
+        t_grid = __builtin_amdgcn_s_memtime();
+#endif
         // ---- what is left are the source chunks, for walkers that cannot use the cells: claimed from the per-XCD queues
         int item = sitem[0];
 #pragma unroll 1
@@ -539,14 +595,18 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #pragma unroll 1
                     for (int w = 0; w < nw; ++w) {
                         if (!((rest >> w) & 1)) continue;
-                        const double* __restrict__ r = wrec + (size_t)(w0 + w) * REC;
-                        const int mode = wmode[((size_t)(w0 + w) * MAXF + fld) * WM];
+                        // (the walker's record: in memory, or - one-launch form - in LDS: scalars in wsc, per-field values in wfc / wlf)
+                        const double* __restrict__ r = FUSED ? wsc + w * 8 : wrec + (size_t)(w0 + w) * REC;
+                        const double* __restrict__ rf = wfc + (w * MAXF + fld) * 8;
+                        const int mode = FUSED ? uni(*reinterpret_cast<const int*>(rf + 4)) : wmode[((size_t)(w0 + w) * MAXF + fld) * WM];
+                        const double r_lf = FUSED ? wlf[w * MAXF + fld] : r[RF(fld, F_LF)];
+                        const double r_v = FUSED ? rf[F_V] : r[RF(fld, F_V)], r_ca = FUSED ? rf[F_CA] : r[RF(fld, F_CA)];
                         double acc = 0.0;
                         int form;
                         if (mode == MODE_SLOW) {
                             form = FORM_CAREFUL;
                             const WFree wf{r[R_LSTAR], r[R_C0] + kc.lnom0_src[fld], r[R_C1], r[R_Q], r[R_ALPHAC],
-                                           r[RF(fld, F_LF)], r[RF(fld, F_V)], kc.lnom0_src[fld], 0.0};
+                                           r_lf, r_v, kc.lnom0_src[fld], 0.0};
 #pragma unroll 1
                             for (int i = t; i < n; i += PB) {
                                 const size_t g = (size_t)s0 + i;
@@ -555,8 +615,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                         } else {
                             WFree wf{};
                             wf.alphaC = r[R_ALPHAC];
-                            wf.cA = r[RF(fld, F_CA)];
-                            wf.V = r[RF(fld, F_V)];
+                            wf.cA = r_ca;
+                            wf.V = r_v;
                             const bool upper = kc.specialise && wf.alphaC > 0.0 && fma(wf.alphaC, a1_first, wf.cA) >= 0.0;
                             if (upper && u_first * wf.V > 37.5) {
                                 form = FORM_GENERAL_NOEXP;
@@ -618,7 +678,7 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int nB = fa.nchB > 0 ? fa.nslot : 0, nC = fa.nchC > 0 ? fa.nslot : 0;
                 if (v < nw)
                     finalize_wave<true>(fa.partA, fa.nchA, fa.nchA, fa.partB, nB, nB, nC > 0 ? fa.partC : nullptr, nC, (int)STAT_CELLS,
-                                        fa.wstat_w, fa.wbase_w, w0 + v, t & 63, AcceptArgs{}, fa.out, nullptr, nullptr);
+                                        sstat - w0, sbase - w0, w0 + v, t & 63, AcceptArgs{}, fa.out, nullptr, nullptr);
                 if (t < QSTRIDE) q[t] = 0;        // the tile's counters, for the next launch
             }
         }
@@ -626,12 +686,26 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #ifdef LF_STAMPS
     if (stamp && tid == 0) {
         stamp[1] = __builtin_amdgcn_s_memtime();
+        const bool noitems = nitems_done == 0;
         stamp[2] = (unsigned long long)nitems_done;
-        stamp[3] = t_first ? t_first - stamp[0] : 0;      // prologue: tables, tile constants, first claim
-        stamp[4] = t_sw;                                  // catalogue items: barrier D, loads, LDS transposition (wave 0's view)
-        stamp[7] = t_loop;                                //                  walker loops
+        if (noitems) {
+            // no source items (every walker on the cells: the normal case): the time line of the one launch instead - tables +
+            // preparation + records up to t_prep, the cells up to t_cells, the grid up to t_grid, count and final sums after
+            stamp[3] = t_prep - stamp[0];
+            stamp[4] = t_cells - stamp[0];
+            stamp[7] = t_grid - stamp[0];
+            // (the preparation's inner time line goes where the items count would be: 4 x 16 bits, units of 16 cycles)
+            unsigned long long pk = 0;
+            for (int i = 0; i < 4; ++i) pk |= (((s_tprep[i + 1] - stamp[0]) >> 4) & 0xffffull) << (16 * i);
+            stamp[2] = pk;
+        } else {
+            stamp[3] = t_first ? t_first - stamp[0] : 0;      // prologue: tables, tile constants, first claim
+            stamp[4] = t_sw;                                  // catalogue items: barrier D, loads, LDS transposition (wave 0's view)
+            stamp[7] = t_loop;                                //                  walker loops
+        }
         stamp[6] = __builtin_amdgcn_s_memrealtime();
-        kc.stamps[(size_t)gridDim.x * 8 + blockIdx.x] = t_red;      // barrier C, reduction, stores  (second table behind the first)
+        kc.stamps[(size_t)gridDim.x * 8 + blockIdx.x] =             // barrier C, reduction, stores  (second table behind the first)
+            !noitems ? t_red : (((s_ttab - stamp[0]) << 32) | ((t_p0 - stamp[0]) & 0xffffffffull));
     }
 #endif
 }

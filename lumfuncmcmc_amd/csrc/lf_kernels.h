@@ -286,11 +286,24 @@ __device__ __forceinline__ int key_floor(double v) {
 // 8 x 16 LDS staging area `sth`.  BLOCK_SYNC: the 64 lanes are a workgroup of their own (lf_prepare) and meet at a
 // barrier; otherwise they are one wave of a larger workgroup (lf_free's fused prologue), in lockstep anyway.
 // nqueue > 0: the launch is lf_free's (the table keys and the cells' flag are wanted).
-template <bool BLOCK_SYNC>
+template <bool BLOCK_SYNC, bool TOLDS = false>
 __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& sp, const double* __restrict__ theta, int B,
                                              double* __restrict__ wrec, int* __restrict__ wstat,
                                              int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
-                                             int nqueue, int wq, int f, int grp, double (*sth)[16]) {
+                                             int nqueue, int wq, int f, int grp, double (*sth)[16],
+                                             double* __restrict__ l_fc = nullptr, double* __restrict__ l_sc = nullptr,
+                                             int* __restrict__ l_stat = nullptr, double* __restrict__ l_base = nullptr,
+                                             double* __restrict__ l_lf = nullptr, unsigned long long* tst = nullptr) {
+#ifdef LF_STAMPS
+#define LF_TST(i) do { if (tst && wq % 8 == 0 && f == 0) tst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LF_TST(i) do { } while (0)
+#endif
+    LF_TST(0);
+    // TOLDS (lf_free's one-launch form, FREE): the records go to the tile's LDS arrays INSTEAD of memory - l_fc per (walker,
+    // field) 8 doubles {alpha_C, V, cA, cY - H_LO - 1 / (2 H_INV), {mode, klo, khi, kne, kaC} as ints, cY - H_LO}, l_lf per
+    // (walker, field) lF, l_sc per walker the 5 scalars, l_stat the status word, l_base the closed-form part of piece A: the
+    // launch that makes them is the only one that reads them, and nobody waits for a trip through memory
     const bool live = wq < B;
     const int w = live ? wq : B - 1;                 // idle groups replay the last walker, write nothing
     const bool has_f = f < kc.nf;
@@ -310,9 +323,15 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
         }
         if (live && f == 0) sp.zz[w] = z;
     } else {
-        for (int i = f; i < kc.ndim; i += 8) sth[grp][i] = theta[(size_t)w * kc.ndim + i];
+        // (ndim <= 16: two elements per lane, both loads issued before either is waited for)
+        const double* __restrict__ row = theta + (size_t)w * kc.ndim;
+        double t0 = row[min(f, kc.ndim - 1)], t1 = row[min(f + 8, kc.ndim - 1)];
+        asm volatile("" : "+v"(t0), "+v"(t1));
+        if (f < kc.ndim) sth[grp][f] = t0;
+        if (f + 8 < kc.ndim) sth[grp][f + 8] = t1;
     }
     if (BLOCK_SYNC) __syncthreads();
+    LF_TST(1);
     const double* th = sth[grp];
     double* r = wrec + (size_t)w * REC;
     const double SAFE = -700.0;
@@ -353,7 +372,8 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             quad_range(aL, bL, cL, kc.z_lo[f], kc.z_hi[f], lsmn, lsmx);
             quad_range(aP, bP, cP, kc.z_lo[f], kc.z_hi[f], phmn, phmx);
             const double tmax = kc.lum_max[f] - lsmn, tmin = kc.lum_min[f] - lsmx;
-            const double vb = exp10(tmax);
+            // an UPPER bound of 10^tmax is all the test needs (single-precision hardware exp2, rounded up; NaN fails the test)
+            const double vb = tmax < 2.9 ? (double)(__builtin_amdgcn_exp2f((float)tmax * 3.3219285f) * 1.0001f) + 1.0e-30 : 1.0e300;
             const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
             m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
             // closed-form part: sum_i [ln Om_i + ln ln10 + ln10 phi*(z_i) + c1 (lum_i - L*(z_i))]; only
@@ -375,12 +395,15 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
         ok = ok && (alphaC >= kc.lims[LF_LIM_ALPHA][0]) && (alphaC <= kc.lims[LF_LIM_ALPHA][1]);
         const double c0 = LF_LNLN10 + LF_LN10 * phistar, c1 = LF_LN10 * (al + 1.0);
         const double Q = exp10(LF_LREF - Lstar);
+        asm volatile("" : "+v"(const_cast<double&>(Q)));
+        LF_TST(2);
         if (live && f == 0) {
-            r[R_LSTAR] = Lstar;
-            r[R_C0] = c0;
-            r[R_C1] = c1;
-            r[R_Q] = Q;
-            r[R_ALPHAC] = alphaC;
+            double* d = TOLDS ? l_sc + grp * 8 : r;
+            d[R_LSTAR] = Lstar;
+            d[R_C0] = c0;
+            d[R_C1] = c1;
+            d[R_Q] = Q;
+            d[R_ALPHAC] = alphaC;
         }
         if (has_f) {
             const double Flim = kc.variant == LF_FREE ? th[k + f] : kc.flim0[f];
@@ -407,7 +430,20 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                 // the field's cells can stand for its sources when all of them lie inside the tables for this walker
                 // (their width was chosen for the prior box's largest alpha_C: lfmcmc.hip, build_cells)
                 cell_ok = kc.nsrc[f] == 0 || (klo <= kc.kf_first[f] && kc.kf_last[f] <= khi);
-                if (live) {
+                if (live && TOLDS) {
+                    double* d = l_fc + (grp * MAXF + f) * 8;
+                    int* di = reinterpret_cast<int*>(d + 4);
+                    d[0] = alphaC;
+                    d[F_V] = V;
+                    d[F_CA] = cA;
+                    d[F_CY] = cY - H_LO - 0.5 / H_INV;      // (the h table's index arithmetic wants y - H_LO, and that minus half a piece)
+                    d[7] = cY - H_LO;
+                    di[M_KLO] = klo;
+                    di[M_KHI] = khi;
+                    di[M_KNE] = kne;
+                    di[M_KAC] = kac;
+                    l_lf[grp * MAXF + f] = lF;
+                } else if (live) {
                     r[RF(f, F_LF)] = lF;
                     r[RF(f, F_V)] = V;
                     r[RF(f, F_CA)] = cA;
@@ -419,6 +455,7 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                     km[M_KAC] = kac;
                 }
             }
+            LF_TST(3);
             if (kc.nsrc[f] > 0) {
                 const double vmax = kc.pmax[f] * Q;       // the very product the kernels form for that source
                 const double tlo = kc.lum_min[f] - Lstar, thi = kc.lum_max[f] - Lstar;
@@ -427,9 +464,20 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                     m = MODE_NEGINF;
                     neginf = 1;
                 } else if (kc.variant == LF_FREE) {
+                    // A LOWER bound of ln Omega of the field's faintest source is all the test needs, and the threshold is
+                    // -700: elementary inequalities and single-precision hardware log instead of the device library's log, rsqrt
+                    // and exp (this chain, on one wave, was a good part of the 7 us a tile's preparation took inside lf_free):
+                    //   fc = 1 / (2 s (s - num)), s = sqrt(1 + num^2) <= 1 + |num|   =>   ln fc >= -2 ln(2 (1 + |num|))   (num < 0)
+                    //   fc >= 1/2                                                                                        (num >= 0)
+                    //   1 - e^-x >= x / (1 + x)                                   =>   ln fc / (1 - e^-x) >= ln fc (1 + 1 / x)
+                    // (a NaN anywhere fails the comparisons: careful path.)  Looser than the exact value by at most ln 2 and a
+                    // factor 1.3 - immaterial 700 e-folds away, and erring towards the careful path.
                     const double num = alphaC * (kc.a_min[f] - lF);
-                    const double lnfc = log(0.5 * (1.0 + num * rsqrt(fma(num, num, 1.0))));
-                    const double lnOm = kc.lnom0_src[f] + lnfc / (1.0 - exp(-kc.u_min[f] * V));
+                    const float an = (float)fmax(-num, 0.0);
+                    const float lnfc_lo = num >= 0.0 ? -0.6932f
+                                                     : -2.00002f * 0.69314724f * __builtin_amdgcn_logf(2.0f * (1.0f + an) * 1.000001f) - 0.01f;
+                    const float x = (float)(kc.u_min[f] * V) * 0.999999f;
+                    const double lnOm = kc.lnom0_src[f] + (double)(lnfc_lo * (1.0f + 1.000001f / x));
                     // fexp_neg takes |x| < 2^24 unclamped: screen the largest f / f_tau of the field as well
                     m = (lbT > SAFE && lnOm > SAFE && lbT + lnOm > SAFE && kc.u_max[f] * V < 1.0e6) ? MODE_FAST : MODE_SLOW;
                 } else {
@@ -442,6 +490,7 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             }
         }
     }
+    LF_TST(4);
     base = group8_sum(base);
     const int bad = group8_or(ok ? 0 : 1);
     neginf = group8_or(neginf);
@@ -453,11 +502,20 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     // cells: only walkers whose every field is FAST and inside the tables (all the others are rare, and summed per source)
     const int nocell = group8_or(has_f && !(cell_ok && (m == MODE_FAST || kc.nsrc[f] == 0)) ? 1 : 0);
     const int cells = kc.cells && (kc.variant == LF_FREE ? nqueue > 0 : kc.variant == LF_ZEVOL) && !bad && !neginf && !nocell;
-    if (live && has_f) wmode[((size_t)w * MAXF + f) * WM + M_MODE] = m;
+    if (live && has_f) {
+        if (TOLDS) reinterpret_cast<int*>(l_fc + (grp * MAXF + f) * 8 + 4)[M_MODE] = m;
+        else wmode[((size_t)w * MAXF + f) * WM + M_MODE] = m;
+    }
     if (live && f == 0) {
-        wbase[w] = base;
-        wstat[w] = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0) | (cells ? STAT_CELLS : 0);
-        if (slow && slow_list) slow_list[1 + atomicAdd(slow_list, 1)] = w;
+        const int st = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0) | (cells ? STAT_CELLS : 0);
+        if (TOLDS) {
+            l_base[grp] = base;
+            l_stat[grp] = st;
+        } else {
+            wbase[w] = base;
+            wstat[w] = st;
+            if (slow && slow_list) slow_list[1 + atomicAdd(slow_list, 1)] = w;
+        }
     }
 }
 
@@ -465,6 +523,7 @@ __global__ __launch_bounds__(64) void lf_prepare(KConst kc, StepArgs sp, const d
                                                  double* __restrict__ wrec, int* __restrict__ wstat,
                                                  int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
                                                  int* __restrict__ queue, int nqueue) {
+    warm_kernarg<sizeof(KConst) + sizeof(StepArgs) + 7 * 8 + 8>();      // (lf_math.h: the arguments in one round trip)
     __shared__ double sth[8][16];
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt < nqueue) queue[gt] = 0;                  // item counters of the lf_free launch that follows (8 B threads >= 9 B / 8)
@@ -1340,6 +1399,8 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
                                                  int B, Tiling tl, int nchA, int ntilesB, int twb, int nblkB,
                                                  double* __restrict__ partA, int strideA,
                                                  double* __restrict__ partB, int strideB, Rescue rs, GridC gc, ZCells zc) {
+    warm_kernarg<sizeof(KConst) + sizeof(SrcArrays) + sizeof(NodeArrays) + 2 * 8 + 4 + sizeof(Tiling) + 4 * 4 + 16 + 16 + sizeof(Rescue) +
+                 sizeof(GridC) + sizeof(ZCells)>();      // (lf_math.h: the arguments in one round trip)
     __shared__ MathTables tab;
     __shared__ __attribute__((aligned(16))) double red[(TW > TWB ? TW : TWB) * BLOCK];
     __shared__ double Tw[CMP ? GRIDC_MAX_S : 1];
@@ -1558,6 +1619,7 @@ __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ par
                                                   const double* __restrict__ wbase, int B, AcceptArgs ap,
                                                   double* __restrict__ out, double* __restrict__ outA,
                                                   double* __restrict__ outB, int* __restrict__ slow_list, int a_flag) {
+    warm_kernarg<12 * 8 + 6 * 4 + sizeof(AcceptArgs)>();      // (lf_math.h: the arguments in one round trip)
     const int w = blockIdx.x;
     if (w >= B) return;
     if (slow_list && w == 0 && threadIdx.x == 0) slow_list[0] = 0;     // lf_main has consumed the list

@@ -135,19 +135,26 @@ struct TermTables {
 };
 // All loads are issued before the first LDS store (fixed trip counts, NT threads): the prologue of a workgroup pays ONE
 // round trip to L2 for the 27 KB, not one per loop iteration.
+// (t: this thread's rank among the NT that take part; default: the whole workgroup)
 template <int NT>
-__device__ __forceinline__ void load_term_tables(TermTables* tt) {
+__device__ __forceinline__ void load_term_tables(TermTables* tt, int t = -1) {
     double2* g2 = reinterpret_cast<double2*>(tt->g);
     double2* h2 = reinterpret_cast<double2*>(tt->h);
     const double2* G2 = reinterpret_cast<const double2*>(G_TABLE);
     const double2* H2 = reinterpret_cast<const double2*>(H_TABLE);
     constexpr int NG = (G_N * 4 + NT - 1) / NT, NH = (H_N * 4 + NT - 1) / NT;
     double2 vg[NG], vh[NH];
-    const int t = threadIdx.x;
+    if (t < 0) t = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < NG; ++q) vg[q] = G2[min(t + q * NT, G_N * 4 - 1)];
 #pragma unroll
     for (int q = 0; q < NH; ++q) vh[q] = H2[min(t + q * NT, H_N * 4 - 1)];
+    // (every load is issued before the first is waited for: without this the compiler sinks each load into the guarded
+    // block of its store - seven dependent round trips to a cold L2 for the workgroup's tables, 3.8 us of a 19-us launch)
+#pragma unroll
+    for (int q = 0; q < NG; ++q) asm volatile("" : "+v"(vg[q].x), "+v"(vg[q].y));
+#pragma unroll
+    for (int q = 0; q < NH; ++q) asm volatile("" : "+v"(vh[q].x), "+v"(vh[q].y));
 #pragma unroll
     for (int q = 0; q < NG; ++q)
         if (t + q * NT < G_N * 4) g2[t + q * NT] = vg[q];
@@ -208,6 +215,50 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Kernel arguments: one round trip instead of a dozen.  A launch's kernarg segment is freshly written memory - nothing of
+// it is in the scalar cache or in L2 - and these kernels take ~1.5 KB of arguments (KConst alone is 1360 bytes) which the
+// compiler fetches with s_load instructions hoisted to the top of the kernel, one s_waitcnt after the other because it
+// spills them to VGPR lanes as they arrive: twelve dependent misses in lf_free's preamble, ~0.6 us each from device
+// memory (measured: 19.0 us per evaluation with the kernarg ring in device memory, 32.2 us with it in host memory,
+// HIP_FORCE_DEV_KERNARG=0: thirteen misses' worth of PCIe).  warm_kernarg issues loads of the whole segment back to
+// back, the results discarded, and waits once: afterwards every line is in the scalar cache (and in L2 for the vector
+// loads of fields indexed per lane).  BYTES = the size of the explicit arguments; the over-read up to the next multiple
+// of 256 stays inside the segment (the hidden arguments that follow are 256 bytes).
+// ----------------------------------------------------------------------------------------------
+#define LF_KW1(o) "s_load_dwordx16 %0, %1, " #o "\n\t"
+#define LF_KW4(b) LF_KW1(b + 0x00) LF_KW1(b + 0x40) LF_KW1(b + 0x80) LF_KW1(b + 0xc0)
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg() {
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    constexpr int N4 = (BYTES + 255) / 256;
+    static_assert(N4 >= 1 && N4 <= 10, "extend the ladder");
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    v16i t;
+    if constexpr (N4 == 1) asm volatile(LF_KW4(0x000) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 2) asm volatile(LF_KW4(0x000) LF_KW4(0x100) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 3) asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 4)
+        asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) LF_KW4(0x300) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 5)
+        asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) LF_KW4(0x300) LF_KW4(0x400) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 6)
+        asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) LF_KW4(0x300) LF_KW4(0x400) LF_KW4(0x500) "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 7)
+        asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) LF_KW4(0x300) LF_KW4(0x400) LF_KW4(0x500) LF_KW4(0x600) "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 8)
+        asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) LF_KW4(0x300) LF_KW4(0x400) LF_KW4(0x500) LF_KW4(0x600) LF_KW4(0x700)
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 9)
+        asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) LF_KW4(0x300) LF_KW4(0x400) LF_KW4(0x500) LF_KW4(0x600) LF_KW4(0x700)
+                     LF_KW4(0x800) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
+    if constexpr (N4 == 10)
+        asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) LF_KW4(0x300) LF_KW4(0x400) LF_KW4(0x500) LF_KW4(0x600) LF_KW4(0x700)
+                     LF_KW4(0x800) LF_KW4(0x900) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
 }
 
 }  // namespace lf

@@ -44,7 +44,9 @@ def test_bins_equal_the_lattice(n, rows):
     assert np.array_equal(np.isnan(b1), np.isnan(b0)) and np.array_equal(np.isinf(lp1), np.isinf(lp0))
     assert np.isinf(lp1[7]) and np.isinf(lp1[9])
     fin = np.isfinite(b0)
-    np.testing.assert_array_equal(a1[fin], a0[fin])          # piece A does not depend on the option
+    # piece A does not depend on the option - up to the order of its partial sums when the launch has another geometry
+    # (fewer grid chunks: fewer workgroups for a small catalogue)
+    np.testing.assert_allclose(a1[fin], a0[fin], rtol=2e-15)
     # proven: 1e-15 of piece B in exact arithmetic; in binary64 both sums also carry the rounding of their nodes' log flux
     # (values near -17 are 1.8e-15 apart, and d ln F / d log f reaches ~100 at the faint end)
     rel = np.abs(b1[fin] - b0[fin]) / np.abs(b0[fin])

@@ -129,11 +129,18 @@ def test_census_adds_up():
     ctx.set_option("count_forms", 1)
     ctx.lnprob_batch(th)
     fc = ctx.form_counts()
+    nbins = ctx.last_launch()["chunks_b"]
+    ctx.set_option("grid_shortcut", 0)
+    ctx.set_option("count_forms", 1)
+    ctx.lnprob_batch(th)
+    fc0 = ctx.form_counts()
     ctx.close()
     src = sum(fc[k] for k in ("general", "general_noexp", "table", "table_noexp", "careful", "skipped"))
     assert src == 40 * 250000, fc
     assert fc["skipped"] == 250000
-    assert fc["node_general"] + fc["node_bright"] == 39 * 101 * 101 * 5, fc
+    # piece B: 64 nodes per flux bin (lf_gridbound.h) x 5 fields, or the lattice's 101 x 101 points x 5 fields
+    assert nbins <= 32 and fc["node_general"] + fc["node_bright"] == 39 * nbins * 64 * 5, fc
+    assert fc0["node_general"] + fc0["node_bright"] == 39 * 101 * 101 * 5, fc0
 
 
 @pytest.mark.parametrize("n,B,cells", [(60001, 597, 1), (60001, 597, 0), (400003, 130, 1), (400003, 9, 0), (1000000, 128, 1)])
