@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblfmcmc.so")
 SOURCES = [os.path.join(CSRC, "lfmcmc.hip")]
-HEADERS = [os.path.join(CSRC, h) for h in ("lf_kernels.h", "lf_free.h", "lf_math.h", "lf_tables.h", "lf_compress.h", "lf_gridbound.h")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("lf_kernels.h", "lf_free.h", "lf_pers.h", "lf_math.h", "lf_tables.h", "lf_compress.h", "lf_gridbound.h")] + \
           [os.path.join(os.path.dirname(HERE), "include", "lfmcmc.h")]
 
 

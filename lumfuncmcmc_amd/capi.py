@@ -388,10 +388,10 @@ class LFContext(object):
         self._check(self._lib.lf_last_launch(self._h, n))
         d = dict(zip(("st", "tw", "twb", "kind", "workgroups", "chunks_a", "chunks_b", "rows"), (int(v) for v in n)))
         d["compressed"] = int(d["kind"] == 1)
-        d["fused"] = d["kind"] == 3                 # lf_free doing lf_prepare's and lf_finalize's work too: one launch
+        d["fused"] = d["kind"] in (3, 5)            # lf_free / lf_pers doing lf_prepare's and lf_finalize's work too: one launch
         if d["fused"]:
-            d["kind"] = 2
-        d["kernel"] = "lf_free<%d>" % d["st"] if d["kind"] == 2 else "lf_main"
+            d["kind"] -= 1
+        d["kernel"] = "lf_free<%d>" % d["st"] if d["kind"] == 2 else ("lf_pers" if d["kind"] == 4 else "lf_main")
         return d
 
     def set_option(self, key, value):

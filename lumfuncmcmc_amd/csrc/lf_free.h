@@ -26,6 +26,12 @@ namespace lf {
 constexpr int PB = 512;      // threads per persistent workgroup: 8 waves
 constexpr int PTW = 8;       // walkers per tile
 constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalogue queues of XCD 0..7
+// The cells' and the grid's chunks of a tile are dealt to VF VIRTUAL workgroups, and partB / partC hold one partial sum per
+// (walker, virtual workgroup): the workgroups that actually serve the tile (at most VF: 32 at 128 rows, 16 at 256, 8 when a
+// group serves several tiles in turn) take the virtual ranks r, r + fgroup, ... and keep their sums apart.  So a walker's
+// partial sums - and with them the bits of its lnprob - do not depend on how many rows share its call, on its place in
+// the batch, or on how a batch is sharded over GPUs.
+constexpr int VF = 32;
 
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
 // (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
@@ -297,15 +303,17 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         // cells in flight while the current one is summed - and writes one partial per chunk from the DPP network.
         {
             const int v = wave_base >> 6;
-            // A wave adds up its lanes' values over ALL its chunks and reduces them once: one partial per (walker, workgroup)
-            // (the chunks are dealt statically, so the order of the sums is fixed by the launch geometry).
+            // A wave adds up its lanes' values over ALL the chunks of a virtual rank and reduces them once: one partial per
+            // (walker, virtual workgroup) (the chunks are dealt statically: the order of the sums is fixed by the context).
+#pragma unroll 1
+            for (int vr = frank; vr < VF; vr += fgroup) {
             double acc = 0.0;
             // Who gets which chunk.  The workgroups of ranks >= fgroup / 2 are the YOUNGER ones of their CUs (the launch fills one
             // slot of every CU before the second) and run ~2 us behind their elders in every phase (tools/stamps_fused.py), and
-            // a bin of the grid costs three cell chunks: so the bins go to the elders (rank c mod fgroup, from 0 up) and the
-            // cell chunks are dealt from the middle (chunk cc to rank (cc + fgroup / 2) mod fgroup): the younger half gets cells
-            // first and no bins.  Fixed by the launch geometry alone - not by which walkers are on the cells.
-            const int cfirst = (frank - fgroup / 2 + fgroup) % fgroup;
+            // a bin of the grid costs three cell chunks: so the bins go to the elders (rank c mod VF, from 0 up) and the
+            // cell chunks are dealt from the middle (chunk cc to rank (cc + VF / 2) mod VF): the younger half gets cells
+            // first and no bins.
+            const int cfirst = (vr - VF / 2 + VF) % VF;
             if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && cfirst < fa.nchC) {       // (wave-uniform)
                 // (Nothing but these loads goes through the vector memory counter inside the loop - chunk cc starts at cell
                 // 64 cc, its field comes from KConst by scalar compares, pads need no masking - so the next chunk's cells
@@ -331,11 +339,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 double nx[CELL_REC];
                 load_cells(nx, cfirst);
 #pragma unroll 1
-                for (int cc = cfirst; cc < fa.nchC; cc += fgroup) {
+                for (int cc = cfirst; cc < fa.nchC; cc += VF) {
                     double cd[CELL_REC];
 #pragma unroll
                     for (int k = 0; k < CELL_REC; ++k) cd[k] = nx[k];
-                    if (cc + fgroup < fa.nchC) load_cells(nx, cc + fgroup);
+                    if (cc + VF < fa.nchC) load_cells(nx, cc + VF);
                     const WalkerK p = fetch(v, field_of(cc));
                     asm volatile("; LF_BEGIN cell items=1");
                     acc += cell_sum(cd, p, &tt);
@@ -347,9 +355,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 acc = wave_sum_dpp(acc);          // lane 63: the wave's total
                 const int ln = fresh_tid() & 63;
                 double* __restrict__ row = fa.partC + (size_t)(w0 + v) * fa.nslot;
-                if (ln == 63) pstore(row + frank, acc);
-                if (frank == 0)
-                    for (int i = fgroup + ln; i < fa.nslot; i += 64) pstore(row + i, 0.0);       // (slots of workgroups this tile does not have)
+                if (ln == 63) pstore(row + vr, acc);
+            }
             }
         }
 #ifdef LF_STAMPS
@@ -363,9 +370,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         if (fa.nbq > 0) {
             const int v = wave_base >> 6;
             const int nq = fa.nbq;
+#pragma unroll 1
+            for (int vr = frank; vr < VF; vr += fgroup) {
             double bsum = 0.0;
-            // (bin c goes to the workgroup of rank c mod fgroup: see the cells' deal above)
-            const int first = frank;
+            // (bin c goes to the virtual workgroup of rank c mod VF: see the cells' deal above)
+            const int first = vr;
             if (v < nw && first < nq) {
                 const double* __restrict__ sc = wsc + v * 8;
                 const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (v * MAXF) * 8 + 4));
@@ -387,10 +396,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 double* __restrict__ Tl = red + v * 64;      // this wave's Schechter values, one row per lane
                 QRec nx = load_rec(first);
 #pragma unroll 1
-                for (int c = first; c < nq; c += fgroup) {
+                for (int c = first; c < nq; c += VF) {
                     const QRec nd = nx;
                     const int nr = uni(fa.gq_rows[4 * c + 1]), off = uni(fa.gq_rows[4 * c + 2]);
-                    if (c + fgroup < nq) nx = load_rec(c + fgroup);
+                    if (c + VF < nq) nx = load_rec(c + VF);
                     if (mine(c)) {
                         const int lane = fresh_tid() & 63;
                         const double* __restrict__ om = fa.gq_omega + off + lane;
@@ -429,9 +438,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 bsum = wave_sum_dpp(bsum);        // lane 63: the wave's total
                 const int ln = fresh_tid() & 63;
                 double* __restrict__ row = fa.partB + (size_t)(w0 + v) * fa.nslot;
-                if (ln == 63) pstore(row + frank, bsum);
-                if (frank == 0)
-                    for (int i = fgroup + ln; i < fa.nslot; i += 64) pstore(row + i, 0.0);
+                if (ln == 63) pstore(row + vr, bsum);
+            }
             }
         } else
         // ---- ... or over the lattice: 64 nodes per chunk, one WALKER PER WAVE (lane = node), every wave
@@ -441,8 +449,10 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
         {
             const int v = wave_base >> 6;
             const int nch64 = fa.nchB;            // chunks of 64 nodes
+#pragma unroll 1
+            for (int vr = frank; vr < VF; vr += fgroup) {
             double bsum = 0.0;
-            if (v < nw && frank < nch64) {
+            if (v < nw && vr < nch64) {
                 const double* __restrict__ sc = wsc + v * 8;
                 const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (v * MAXF) * 8 + 4));
                 // per-field constants of this walker as the grid forms expect them: r[RF(f, F_CA)], r[RF(f, F_V)]
@@ -462,11 +472,11 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                     const double2 a = src[0], b = src[1], d = src[2];
                     return Node{a.x, a.y, b.x, b.y, d.x, d.y};
                 };
-                Node nx = load_nodes(frank);      // the next chunk's nodes are in flight while the current one is summed
+                Node nx = load_nodes(vr);      // the next chunk's nodes are in flight while the current one is summed
 #pragma unroll 1
-                for (int c = frank; c < nch64; c += fgroup) {
+                for (int c = vr; c < nch64; c += VF) {
                     const Node nd = nx;
-                    if (c + fgroup < nch64) nx = load_nodes(c + fgroup);
+                    if (c + VF < nch64) nx = load_nodes(c + VF);
                     if (mine(c)) {
                         const double a4min = uni(nd.a4min);            // the chunk's faintest node, for the bright form of the field sum
                         const double T = fexp_c(fma(uni(sc[R_C1]), nd.G - uni(sc[R_LSTAR]), uni(sc[R_C0])) - nd.PG * uni(sc[R_Q]), &tab);
@@ -483,9 +493,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 bsum = wave_sum_dpp(bsum);        // lane 63: the wave's total
                 const int ln = fresh_tid() & 63;
                 double* __restrict__ row = fa.partB + (size_t)(w0 + v) * fa.nslot;
-                if (ln == 63) pstore(row + frank, bsum);
-                if (frank == 0)
-                    for (int i = fgroup + ln; i < fa.nslot; i += 64) pstore(row + i, 0.0);
+                if (ln == 63) pstore(row + vr, bsum);
+            }
             }
         }
 #ifdef LF_STAMPS

@@ -353,16 +353,17 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
         quad_coef(p1, p2, p3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aP, bP, cP);
         const double c1 = LF_LN10 * (al + 1.0);
         if (live && f == 0) {
-            r[Z_AL] = aL; r[Z_BL] = bL; r[Z_CL] = cL;
-            r[Z_AP] = aP; r[Z_BP] = bP; r[Z_CP] = cP;
-            r[Z_C1] = c1;
+            double* d = TOLDS ? l_sc + grp * 8 : r;
+            d[Z_AL] = aL; d[Z_BL] = bL; d[Z_CL] = cL;
+            d[Z_AP] = aP; d[Z_BP] = bP; d[Z_CP] = cP;
+            d[Z_C1] = c1;
         }
         if (live && has_f) {
             // the local form of the term (srcsum_body) expands L*(z) about a lane's middle source: the size of its
             // exponent is bounded by this slope times the lane's width in z (a lane is narrower than 1 / 128 or the
             // chunk's key is 0 and the form is not taken)
             const double s0 = fabs(fma(2.0 * aL, kc.z_lo[f], bL)), s1 = fabs(fma(2.0 * aL, kc.z_hi[f], bL));
-            r[RF(f, 0)] = LF_LN10 * (fmax(s0, s1) + fabs(aL) * (1.0 / 128.0));
+            (TOLDS ? l_fc + (grp * MAXF + f) * 8 : r + RF(f, 0))[0] = LF_LN10 * (fmax(s0, s1) + fabs(aL) * (1.0 / 128.0));
             // the field's cells in redshift can stand for its sources (ZCELL_RHO above; NaN coefficients fail the test)
             cell_ok = kc.nsrc[f] == 0 || (LF_LN10 * fmax(s0, s1) * kc.zcell_rho <= ZCELL_X1 &&
                                           LF_LN10 * fabs(aL) * kc.zcell_rho * kc.zcell_rho <= ZCELL_X2);
@@ -1147,8 +1148,10 @@ __device__ __forceinline__ void gridsum_body(const KConst& kc, const NodeArrays&
     const int w0 = tile * tw;
     const int nw = min(tw, B - w0);
     const int gi = c * BLOCK + tid;
-    const bool valid = gi < na.nnodes;
-    const int g = valid ? gi : 0;
+    // (source-sharded ranks split piece B by GRANULES of 64 nodes - g with g % parts == part - whichever kernel integrates
+    // them: lf_free's and lf_pers's chunks are granules, a workgroup here holds four; a node of another rank's weighs 0)
+    const bool valid = gi < na.nnodes && !(kc.grid_parts > 1 && (gi >> 6) % kc.grid_parts != kc.grid_part);
+    const int g = gi < na.nnodes ? gi : 0;
     const double G = na.G[g], PG = na.PG[g], W = valid ? na.W[g] : 0.0;
     const double a3 = na.a3[g], a4 = na.a4[g];
     const double a4min = VARIANT == LF_FREE ? na.a4min[c] : 0.0;      // wave-uniform
@@ -1410,15 +1413,6 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
         if ((int)blockIdx.x >= first_resc && *rs.slow_count == 0) return;
     }
     int id = blockIdx.x;
-    if (id < nblkB && kc.grid_parts > 1) {
-        // piece B is split over source-sharded ranks: node chunks that belong to another rank contribute 0 here
-        const int c = id / ntilesB;
-        if (c % kc.grid_parts != kc.grid_part) {
-            const int w0 = (id - c * ntilesB) * twb;
-            if ((int)threadIdx.x < min(twb, B - w0)) partB[(size_t)(w0 + threadIdx.x) * strideB + c] = 0.0;
-            return;
-        }
-    }
     constexpr bool ZC = VARIANT == LF_ZEVOL && !CMP;
     const int nsrc_wg = nchA * (tl.ntiles + tl.ntiles_s);
     // item `sid` of the per-source part -> chunk, first walker, walkers

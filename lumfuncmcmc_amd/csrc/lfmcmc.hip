@@ -20,6 +20,7 @@
 #include "lf_gridbound.h"
 #include "lf_kernels.h"
 #include "lf_free.h"
+#include "lf_pers.h"
 
 namespace {
 
@@ -106,6 +107,11 @@ struct lf_ctx {
         int* d_rows = nullptr;
     } gridq;
     int64_t opt_grid_shortcut = 1;      // 0: lf_free integrates the lattice (A/B runs)
+    // FIXCOMP, ZEVOL: the grid's nodes as 32-byte records {G, PG, W, column} padded to chunks of 64, and the columns' redshifts
+    // (lf_pers.h: the persistent kernel of these variants)
+    double *d_nodes4 = nullptr, *d_zcol = nullptr;
+    int nch4 = 0;
+    int slots_pers = 0;                 // workgroups of lf_pers the chip holds at once (0 = not asked yet)
     double* d_partR = nullptr;          // rescue partials [B][chunks of the real catalogue]
     int* d_slow = nullptr;              // {count, walker indices...} of the walkers lf_prepare flagged SLOW (compressed mode)
     int cap_slow = 0;
@@ -581,7 +587,8 @@ int free_groups(lf_ctx* c, int slot, int ntiles, int nchA, int nchB, int nchC) {
             std::fprintf(stderr, "lf_free<%d>: %d workgroups per CU (occupancy API), %d VGPRs, %zu B LDS\n", ST, nb, at.numRegs, at.sharedSizeBytes);
         }
     }
-    const int64_t per_tile = ((int64_t)nchA + nchB + nchC + 7) / 8;
+    // (at most VF workgroups per tile: the cells' and the grid's chunks are dealt to VF virtual workgroups, lf_free.h)
+    const int64_t per_tile = std::min<int64_t>(VF / 8, ((int64_t)nchA + nchB + nchC + 7) / 8);
     return (int)std::max<int64_t>(1, std::min<int64_t>(c->slots_free[slot] / 8, (int64_t)ntiles * std::max<int64_t>(per_tile, 1)));
 }
 
@@ -614,7 +621,7 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     const int g8 = st == 8 ? free_groups<8>(c, slot, ntiles, nchA, nchB, nchC)
                  : st == 4 ? free_groups<4>(c, slot, ntiles, nchA, nchB, nchC) : free_groups<2>(c, slot, ntiles, nchA, nchB, nchC);
     // the grid's and the cells' partial sums: one per (walker, workgroup serving the walker's tile)
-    const int nslot = ntiles <= g8 ? 8 * ((g8 + ntiles - 1) / ntiles) : 8;
+    const int nslot = VF;                  // one per (walker, VIRTUAL workgroup of its tile): independent of the batch
     rc = ensure_workspace(c, B, (size_t)B * std::max(nchA, 1), (size_t)B * nslot, (size_t)B * nslot);
     if (rc != LF_OK) return rc;
     if (ntiles * QSTRIDE > c->cap_queue) {
@@ -670,6 +677,69 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     return LF_OK;
 }
 
+// The z-evolving and fixed-completeness variants in persistent workgroups (lf_pers.h): one launch for a plain evaluation,
+// lf_prepare / lf_pers / lf_finalize for the sampler's steps and the two-piece diagnostics.
+template <int VARIANT>
+int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB, hipStream_t s,
+                   const lf::StepArgs& sp, const lf::AcceptArgs& ap) {
+    using namespace lf;
+    const int ntiles = (B + PTW - 1) / PTW;
+    if (c->slots_pers == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lf_pers<VARIANT, true>, PB, 0) != hipSuccess || nb < 1) nb = 1;
+        c->slots_pers = std::min(nb, 2) * std::max(c->num_cu, 1);      // (two per CU: what the kernel is sized for)
+    }
+    const int nchB = c->opt_skip_grid ? 0 : c->nch4;
+    const int nchC = VARIANT == LF_ZEVOL && c->kc.cells ? (c->ncell + 63) / 64 : 0;
+    // groups of 8 workgroups: no more than the chip holds at once, no more than there is work for
+    const int64_t per_tile = std::max<int64_t>(1, std::min<int64_t>(VF / 8, ((int64_t)nchB + nchC + 7) / 8));
+    const int g8 = (int)std::max<int64_t>(1, std::min<int64_t>(c->slots_pers / 8, (int64_t)ntiles * per_tile));
+    const int nslot = VF;                  // one per (walker, VIRTUAL workgroup of its tile), lf_free.h
+    int rc = ensure_workspace(c, B, (size_t)B * nslot, (size_t)B * nslot, (size_t)B * nslot);
+    if (rc != LF_OK) return rc;
+    if (ntiles * QSTRIDE > c->cap_queue) {
+        LF_HIP(c, hipDeviceSynchronize());
+        release(c->d_queue);
+        c->cap_queue = 0;
+        const int cap = std::max(2 * ntiles * QSTRIDE, 1024);
+        LF_HIP(c, hipMalloc((void**)&c->d_queue, (size_t)cap * sizeof(int)));
+        c->cap_queue = cap;
+        c->queue_zero = false;
+    }
+    const bool fused = c->opt_fuse && !sp.enabled && !ap.enabled && !d_outA && !d_outB && d_out && c->profiling < 2;
+    if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
+    c->last_stream = s;
+    c->any_enqueued = true;
+    c->prof_this = c->profiling > 0 && (c->prof_tick++ % c->opt_profile_every) == 0;
+    if (fused && !c->queue_zero) {
+        LF_HIP(c, hipMemsetAsync(c->d_queue, 0, (size_t)c->cap_queue * sizeof(int), s));
+        c->queue_zero = true;
+    }
+    if (!fused) {
+        Prof p(c, s, 0);
+        hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
+                           c->d_wstat, c->d_wmode, c->d_wbase, (int*)nullptr, c->d_queue, 0);
+    }
+    const PersArgs pa{B, ntiles, nchB, nchC, c->ncell, nslot, g8, c->d_queue, c->d_partA, c->d_partB, c->d_partR, c->d_nodes4, c->d_zcol,
+                      c->d_cells, c->d_lum, c->d_a1, c->d_P, c->d_U, d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat};
+    {
+        Prof p(c, s, 1);
+        const dim3 grid((unsigned)(8 * g8));
+        const int info[8] = {0, PTW, PTW, fused ? 5 : 4, (int)grid.x, nchC, nchB, B};
+        std::memcpy(c->last_launch, info, sizeof(info));
+        if (fused) hipLaunchKernelGGL((lf_pers<VARIANT, true>), grid, dim3(PB), 0, s, c->kc, pa);
+        else hipLaunchKernelGGL((lf_pers<VARIANT, false>), grid, dim3(PB), 0, s, c->kc, pa);
+    }
+    if (!fused) {
+        Prof p(c, s, 3);
+        hipLaunchKernelGGL(lf_finalize, dim3(B), dim3(64), 0, s, c->d_partA, nslot, nslot, c->d_partB, nchB > 0 ? nslot : 0, nslot,
+                           nchC > 0 ? (const double*)c->d_partR : (const double*)nullptr, nchC > 0 ? nslot : 0, (int)STAT_CELLS, c->d_wstat,
+                           c->d_wbase, B, ap, d_out, d_outA, d_outB, (int*)nullptr, VARIANT == LF_FIXCOMP ? (int)STAT_SLOW : 0);
+    }
+    LF_HIP(c, hipGetLastError());
+    return LF_OK;
+}
+
 int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_outA, double* d_outB,
             hipStream_t s, const lf::StepArgs* step = nullptr, const lf::AcceptArgs* accept = nullptr) {
     using namespace lf;
@@ -679,8 +749,11 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     if (accept) ap = *accept;
     // the persistent kernel takes the free variant's direct path whenever the catalogue can fill it and no launch
     // geometry of lf_main was asked for explicitly
+    // (source-sharded ranks whose piece B goes over flux bins split the BINS: every rank must then be in lf_free, whatever
+    // the size of its shard - lf_main has no bins)
+    const bool shared_bins = c->kc.variant == LF_FREE && c->kc.grid_parts > 1 && c->gridq.built && c->opt_grid_shortcut && !c->opt_skip_grid;
     if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
-        !(c->opt_compress && c->cmp.built) && (c->N >= 8192 || c->opt_persistent == 2)) {
+        !(c->opt_compress && c->cmp.built) && (c->N >= 8192 || c->opt_persistent == 2 || shared_bins)) {
         // Measured crossover (tools/time_parts.py on a warmed-up device, lf_main / lf_free in us; 128 rows: N = 5e4 33 / 37,
         // 7e4 36 / 38, 1e5 40 / 40, 1.8e5 49 / 49, 2.5e5 60 / 56, 5e5 95 / 72, 1e6 168 / 112; N = 1e6 with 16 / 32 / 64 /
         // 256 rows: 29 / 79, 50 / 56, 91 / 72, 327 / 205; N = 1e5 with 512 rows: 127 / 120): the persistent kernel wins
@@ -698,8 +771,16 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         const bool plain = !sp.enabled && !ap.enabled && !d_outA && !d_outB && c->opt_fuse;
         const bool wins = c->kc.cells ? (plain ? c->N * (int64_t)B >= 1200000 && B >= 32 : c->N * (int64_t)B >= 10000000)
                                       : items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1);
-        if (wins || c->opt_persistent == 2 || c->opt_free_st)
+        if (wins || shared_bins || c->opt_persistent == 2 || c->opt_free_st)
             return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
+    }
+    // z-evolving (with its cells, grid by columns) and fixed completeness: the persistent kernel of lf_pers.h, unless a launch
+    // geometry of lf_main was asked for, the census is on (its counters live in lf_main), or the catalogue is compressed
+    if (c->kc.variant != LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
+        !(c->opt_compress && c->cmp.built) && !c->kc.forms && c->d_nodes4 &&
+        (c->kc.variant == LF_FIXCOMP || (c->kc.cells && c->kc.zgrid_cols && c->kc.S <= PERS_MAXS))) {
+        return c->kc.variant == LF_FIXCOMP ? enqueue_pers_v<LF_FIXCOMP>(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap)
+                                           : enqueue_pers_v<LF_ZEVOL>(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     }
     // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
     const bool cmp = c->opt_compress && c->cmp.built && c->kc.variant != LF_FIXCOMP;
@@ -722,7 +803,8 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     const int nchD = cmp ? ctd->n : 0;
     // rescue workgroups leave at once unless a walker was flagged; still, each costs a dispatch slot: scale with B
     const int nresc = cmp ? std::min(nchD, std::min(1024, std::max(128, 2 * B))) : 0;
-    const bool cgrid = cmp && c->gridc.built && c->opt_compress_grid && !c->opt_skip_grid;
+    // (the compressed grid's chunks are bins of its own: ranks that split piece B keep to the lattice's granules)
+    const bool cgrid = cmp && c->gridc.built && c->opt_compress_grid && !c->opt_skip_grid && c->kc.grid_parts <= 1;
     const int nchB = c->opt_skip_grid ? 0 : (cgrid ? (c->gridc.nb + 15) / 16 : (c->nnodes + BLOCK - 1) / BLOCK);
     // ZEVOL on the real catalogue: walkers lf_prepare flags STAT_CELLS are summed over the cells in redshift (partR)
     const int nchC = !cmp && c->kc.variant == LF_ZEVOL && c->kc.cells ? c->ncchunk : 0;
@@ -1035,6 +1117,8 @@ void free_ctx(lf_ctx* c) {
         int* gi_[] = {g.d_row0, g.d_nrows, g.d_off};
         for (int* b : gi_)
             if (b) hipFree(b);
+        if (c->d_nodes4) hipFree(c->d_nodes4);
+        if (c->d_zcol) hipFree(c->d_zcol);
         if (c->gridq.d_rec) hipFree(c->gridq.d_rec);
         if (c->gridq.d_omega) hipFree(c->gridq.d_omega);
         if (c->gridq.d_rows) hipFree(c->gridq.d_rows);
@@ -1331,6 +1415,27 @@ int build(lf_ctx* c, const lf_desc* d) {
     if ((rc = upload(c, &c->d_W, W.data(), nn)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a3, a3.data(), nn)) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_a4, a4.data(), nn)) != LF_OK) return rc;
+    if (d->variant != LF_FREE) {
+        // lf_pers reads the nodes as 32-byte records {G, PG, W, redshift column}, padded to whole chunks of 64 (pads: W = 0)
+        const size_t nch = (nn + 63) / 64;
+        std::vector<double> n4(nch * 64 * 4, 0.0);
+        for (size_t g = 0; g < nch * 64; ++g) {
+            const size_t gg = std::min(g, nn - 1);
+            double* r = &n4[g * 4];
+            r[0] = G[gg];
+            r[1] = PG[gg];
+            r[2] = g < nn ? W[gg] : 0.0;
+            r[3] = kc.zgrid_cols ? (double)(gg / (size_t)S) : 0.0;      // (column-major lattice: node = k S + j)
+        }
+        if ((rc = upload(c, &c->d_nodes4, n4.data(), n4.size())) != LF_OK) return rc;
+        c->nch4 = (int)nch;
+        std::vector<double> zc((size_t)S * 2);
+        for (int k = 0; k < S; ++k) {
+            zc[(size_t)2 * k] = d->zarr[k];
+            zc[(size_t)2 * k + 1] = d->zarr[k] * d->zarr[k];
+        }
+        if ((rc = upload(c, &c->d_zcol, zc.data(), zc.size())) != LF_OK) return rc;
+    }
     {
         // per chunk of 256 nodes the smallest a4 (FREE; NaN-safe: a NaN node keeps the general form)
         std::vector<double> a4min((nn + lf::BLOCK - 1) / lf::BLOCK, 0.0);

@@ -64,7 +64,9 @@ def test_compressed_matches_direct_and_oracle(variant, n, fsa, B):
     print("%s n=%d: compressed vs direct: lnprob %.2e piece A %.2e piece B %.2e" % (variant, n, rel, relA, relB))
     assert rel < 1e-13 and relA < 1e-13 and relB < 1e-13
     if variant == "zevol":
-        assert np.array_equal(Bp, dB)                              # no grid compression for the z-evolving model
+        # no grid compression for the z-evolving model: the same nodes (the direct path sums them in lf_pers, per wave;
+        # the compressed path in lf_main, per workgroup: another order)
+        np.testing.assert_allclose(Bp, dB, rtol=1e-14)
     if n <= 10000:
         compare_rows(got, O.lnprob_batch(inp, th), inp, th, RTOL)
     for gi in (1, 2, 4, 8):                                        # every instantiated geometry
