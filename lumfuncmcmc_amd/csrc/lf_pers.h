@@ -61,6 +61,7 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
     __shared__ __attribute__((aligned(16))) double wfc[PTW * MAXF * 8];       // per (walker, field): [0] ZEVOL slope bound, ints at [4]: mode
     __shared__ __attribute__((aligned(16))) double qe[VARIANT == LF_ZEVOL ? PTW * PERS_MAXS * 2 : 2];   // per (walker, column): {Q, E}
     __shared__ __attribute__((aligned(16))) double red[PB];                   // prepare's staging; the careful path's reduction
+    __shared__ __attribute__((aligned(16))) double zcl[VARIANT == LF_ZEVOL ? PERS_MAXS * 2 : 2];      // the columns' {z, z^2}
     __shared__ int sstat[PTW];
     __shared__ double sbase[PTW];
     __shared__ int smask[4];               // bit w: [0] walker on the cells, [1] needs the sources, [2] outside the prior (no grid)
@@ -69,6 +70,14 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     const int lane = tid & 63, v = wave_base >> 6;
     bool tables_loaded = false;
+#ifdef LF_STAMPS
+    unsigned long long* stamp = kc.stamps ? kc.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long t_prep = 0, t_cols = 0, t_cells = 0, t_grid = 0;
+    if (stamp && tid == 0) {
+        stamp[0] = __builtin_amdgcn_s_memtime();
+        stamp[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 
 #pragma unroll 1
     for (int tile = ((int)blockIdx.x >> 3) % pa.ntiles; tile < pa.ntiles; tile += pa.tile_stride) {
@@ -93,18 +102,22 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
                 const int t = tid - 64;
                 double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * t);
                 double et = EXP_TABLE[t];
-                asm volatile("" : "+v"(lt.x), "+v"(lt.y), "+v"(et));
+                double2 zz = VARIANT == LF_ZEVOL ? *reinterpret_cast<const double2*>(pa.zcol + 2 * min(t, kc.S - 1)) : double2{0.0, 0.0};
+                asm volatile("" : "+v"(lt.x), "+v"(lt.y), "+v"(et), "+v"(zz.x), "+v"(zz.y));      // (one round trip for all of them)
                 tab.logt[t] = lt;
                 tab.expt[t] = et;
+                if (VARIANT == LF_ZEVOL) *reinterpret_cast<double2*>(zcl + 2 * t) = zz;
             }
         } else {
             if (!tables_loaded && tid >= 256) {
                 const int t = tid - 256;
                 double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * t);
                 double et = EXP_TABLE[t];
-                asm volatile("" : "+v"(lt.x), "+v"(lt.y), "+v"(et));
+                double2 zz = VARIANT == LF_ZEVOL ? *reinterpret_cast<const double2*>(pa.zcol + 2 * min(t, kc.S - 1)) : double2{0.0, 0.0};
+                asm volatile("" : "+v"(lt.x), "+v"(lt.y), "+v"(et), "+v"(zz.x), "+v"(zz.y));
                 tab.logt[t] = lt;
                 tab.expt[t] = et;
+                if (VARIANT == LF_ZEVOL) *reinterpret_cast<double2*>(zcl + 2 * t) = zz;
             }
             if (tid < nw * MAXF) {                // (walker, field): slope bound and mode
                 const int w = tid / MAXF, f = tid - w * MAXF;
@@ -133,25 +146,17 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
             }
         }
         __syncthreads();
+#ifdef LF_STAMPS
+        t_prep = __builtin_amdgcn_s_memtime();
+#endif
         const int cellmask = uni(smask[0]), needmask = uni(smask[1]), outmask = uni(smask[2]);
         const bool mine_w = v < nw;               // this wave's walker exists
         const bool grid_w = mine_w && !((outmask >> v) & 1);      // (outside the prior: the grid is not evaluated, lumfuncmcmc.py:408)
         const double* __restrict__ sc = wsc + v * 8;
 
-        // ---- z-evolving: Q and E of this wave's walker for every redshift column (one exponential per column)
-        if (VARIANT == LF_ZEVOL && grid_w) {
-            const double aL = uni(sc[Z_AL]), bL = uni(sc[Z_BL]), cL = uni(sc[Z_CL]);
-            const double aP = uni(sc[Z_AP]), bP = uni(sc[Z_BP]), cP = uni(sc[Z_CP]), c1 = uni(sc[Z_C1]);
-            for (int k = lane; k < kc.S; k += 64) {
-                const double2 zz = *reinterpret_cast<const double2*>(pa.zcol + 2 * k);
-                const double Ls = quad_nofma(aL, bL, cL, zz.x, zz.y);            // lumfuncmcmc_z.py:66
-                const double ph = quad_nofma(aP, bP, cP, zz.x, zz.y);            // :65
-                double2 o;
-                o.x = fexp_c(LF_LN10 * (LF_LREF - Ls), &tab);
-                o.y = fma(-c1, Ls - LF_LREF, fma(LF_LN10, ph, LF_LNLN10));
-                *reinterpret_cast<double2*>(qe + (v * PERS_MAXS + k) * 2) = o;
-            }
-        }
+#ifdef LF_STAMPS
+        t_cols = __builtin_amdgcn_s_memtime();
+#endif
         // ---- z-evolving: the cells in redshift (lf_kernels.h: ZCELL_M), for walkers flagged STAT_CELLS.  Dealt from the
         // middle rank up, the grid's chunks from rank 0 (lf_free.h: the younger workgroups of a CU run behind the elders)
         if (VARIANT == LF_ZEVOL && pa.nchC > 0 && mine_w) {
@@ -171,14 +176,19 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
                         d[2 * k + 1] = i < pa.ncell ? a.y : 0.0;
                     }
                 };
-                double nx[8];
+                // (two chunks ahead: a chunk's arithmetic is a few hundred cycles, its loads a round trip to a cold L2)
+                double nx[8], nx2[8];
                 if (cfirst < pa.nchC) load_cell(nx, cfirst);
+                if (cfirst + VF < pa.nchC) load_cell(nx2, cfirst + VF);
 #pragma unroll 1
                 for (int cc = cfirst; cc < pa.nchC; cc += VF) {
                     double cd[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) cd[k] = nx[k];
-                    if (cc + VF < pa.nchC) load_cell(nx, cc + VF);
+                    for (int k = 0; k < 8; ++k) {
+                        cd[k] = nx[k];
+                        nx[k] = nx2[k];
+                    }
+                    if (cc + 2 * VF < pa.nchC) load_cell(nx2, cc + 2 * VF);
                     asm volatile("; LF_BEGIN pzcell items=1");
                     const double zc2 = cd[0] * cd[0];
                     const double Lc = quad_nofma(aL, bL, cL, cd[0], zc2);
@@ -203,12 +213,37 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
             if (lane == 63) pstore(row + vr, acc);
             }
         }
+#ifdef LF_STAMPS
+        t_cells = __builtin_amdgcn_s_memtime();
+#endif
         // ---- the grid integral (piece B): 64 nodes per chunk, lane = node, one exponential per node
+        // The chunks are dealt to the virtual ranks in CONTIGUOUS runs (rank vr: chunks [vr cpr, (vr + 1) cpr)): the z-evolving
+        // lattice is stored column by column, so a run touches only a few of the S redshift columns, and what the integrand
+        // takes from the walker depends on the column only (lf_kernels.h: gridsum_body) - Q_wk = 10^(42 - L*_w(z_k)) and E_wk
+        // are made here for the run's columns, one lane each (dealt round-robin every workgroup of a tile needed all S
+        // columns of its walkers: 32 times the exponentials, 2.8k cycles of a 36k-cycle launch).
         if (mine_w) {
+            const int cpr = (pa.nchB + VF - 1) / VF;
 #pragma unroll 1
             for (int vr = frank; vr < VF; vr += fgroup) {
             double bsum = 0.0;
-            if (grid_w && vr < pa.nchB) {
+            const int clo = vr * cpr, chi = min(clo + cpr, pa.nchB);
+            if (VARIANT == LF_ZEVOL && grid_w && clo < chi) {
+                const double aL = uni(sc[Z_AL]), bL = uni(sc[Z_BL]), cL = uni(sc[Z_CL]);
+                const double aP = uni(sc[Z_AP]), bP = uni(sc[Z_BP]), cP = uni(sc[Z_CP]), c1z = uni(sc[Z_C1]);
+                const int k_lo = (clo * 64) / kc.S, k_hi = min((chi * 64 - 1) / kc.S, kc.S - 1);
+                for (int k = k_lo + lane; k <= k_hi; k += 64) {
+                    const double2 zz = *reinterpret_cast<const double2*>(zcl + 2 * k);
+                    const double Lsz = quad_nofma(aL, bL, cL, zz.x, zz.y);           // lumfuncmcmc_z.py:66
+                    const double ph = quad_nofma(aP, bP, cP, zz.x, zz.y);            // :65
+                    double2 o;
+                    o.x = fexp_c(LF_LN10 * (LF_LREF - Lsz), &tab);
+                    o.y = fma(-c1z, Lsz - LF_LREF, fma(LF_LN10, ph, LF_LNLN10));
+                    *reinterpret_cast<double2*>(qe + (v * PERS_MAXS + k) * 2) = o;
+                }
+                __builtin_amdgcn_wave_barrier();      // (this wave's LDS writes are in order before its reads)
+            }
+            if (grid_w && clo < chi) {
                 struct Node {
                     double G, PG, W, col;
                 };
@@ -221,11 +256,11 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
                 auto mine = [&](int c) { return !(kc.grid_parts > 1 && c % kc.grid_parts != kc.grid_part); };
                 const double c1 = uni(sc[VARIANT == LF_ZEVOL ? Z_C1 : R_C1]);
                 const double Ls = uni(sc[R_LSTAR]), c0 = uni(sc[R_C0]), Qf = uni(sc[R_Q]);      // (FIXCOMP)
-                Node nx = load_nodes(vr);
+                Node nx = load_nodes(clo);
 #pragma unroll 1
-                for (int c = vr; c < pa.nchB; c += VF) {
+                for (int c = clo; c < chi; ++c) {
                     const Node nd = nx;
-                    if (c + VF < pa.nchB) nx = load_nodes(c + VF);
+                    if (c + 1 < chi) nx = load_nodes(c + 1);
                     if (!mine(c)) continue;
                     asm volatile("; LF_BEGIN pznode items=1");
                     double e;
@@ -236,6 +271,8 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
                     } else {
                         e = fma(c1, nd.G - Ls, c0) - nd.PG * Qf;
                     }
+                    // (a chunk whose every node has underflowed - the bright end of the grid, 10^(L - L*) > 750 - adds exact zeros)
+                    if (__ballot(e > -750.0) == 0ull) continue;
                     bsum = fma(nd.W, fexp_c(e, &tab), bsum);
                     asm volatile("; LF_END pznode");
                 }
@@ -245,6 +282,9 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
             if (lane == 63) pstore(row + vr, bsum);
             }
         }
+#ifdef LF_STAMPS
+        t_grid = __builtin_amdgcn_s_memtime();
+#endif
         // ---- the careful path (rare): walkers whose bounds do not rule out an underflow are summed over the sources with
         // the reference's own -inf convention (per-term checks, device-library math; lf_kernels.h: srcsum_body's careful
         // branch, same arithmetic).  All the tile's workgroups stride over the catalogue together, field by field.
@@ -326,6 +366,17 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
             }
         }
     }
+#ifdef LF_STAMPS
+    if (stamp && tid == 0) {                      // (tools/stamps_fused.py: the slots of lf_free's time line; [2] = the columns' end)
+        stamp[1] = __builtin_amdgcn_s_memtime();
+        stamp[2] = 0;
+        stamp[3] = t_prep - stamp[0];
+        stamp[4] = t_cells - stamp[0];
+        stamp[7] = t_grid - stamp[0];
+        stamp[6] = __builtin_amdgcn_s_memrealtime();
+        kc.stamps[(size_t)gridDim.x * 8 + blockIdx.x] = ((t_cols - stamp[0]) << 32) | ((t_prep - stamp[0]) & 0xffffffffull);
+    }
+#endif
 }
 
 }  // namespace lf

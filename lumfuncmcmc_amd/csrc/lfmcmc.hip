@@ -262,7 +262,10 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
         for (int f = nf - 1; f >= 0; --f)
             if (c->field_ind[f + 1] <= c->field_ind[f]) kc.cc_fstart[f] = kc.cc_fstart[f + 1];
     }
-    if (nreal == 0 || (size_t)c->N < 4 * nreal) return LF_OK;         // (too few sources per cell to pay)
+    // (too few sources per cell to pay - for a big catalogue: for a small one even cells of one source apiece beat the
+    // per-source path, whose cost is its per-item overhead: 10^3 sources, 16 rows: 23.5 us per evaluation over the sources,
+    // 17.5 in lf_main's three launches, 12 over cells)
+    if (nreal == 0 || ((size_t)c->N < 4 * nreal && c->N > 65536)) return LF_OK;
     int rc;
     if ((rc = upload(c, &c->d_cells, cd.data(), cd.size())) != LF_OK) return rc;
     if ((rc = upload(c, &c->d_cc_start, cst.data(), cst.size())) != LF_OK) return rc;
@@ -753,7 +756,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     // the size of its shard - lf_main has no bins)
     const bool shared_bins = c->kc.variant == LF_FREE && c->kc.grid_parts > 1 && c->gridq.built && c->opt_grid_shortcut && !c->opt_skip_grid;
     if (c->kc.variant == LF_FREE && c->opt_persistent && c->opt_geometry < 0 && c->opt_walker_tile == 0 && !c->opt_taper &&
-        !(c->opt_compress && c->cmp.built) && (c->N >= 8192 || c->opt_persistent == 2 || shared_bins)) {
+        !(c->opt_compress && c->cmp.built) && (c->N >= 8192 || c->kc.cells || c->opt_persistent == 2 || shared_bins)) {
         // Measured crossover (tools/time_parts.py on a warmed-up device, lf_main / lf_free in us; 128 rows: N = 5e4 33 / 37,
         // 7e4 36 / 38, 1e5 40 / 40, 1.8e5 49 / 49, 2.5e5 60 / 56, 5e5 95 / 72, 1e6 168 / 112; N = 1e6 with 16 / 32 / 64 /
         // 256 rows: 29 / 79, 50 / 56, 91 / 72, 327 / 205; N = 1e5 with 512 rows: 127 / 120): the persistent kernel wins
@@ -769,8 +772,10 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         const int64_t ntiles = (B + PTW - 1) / PTW;
         const int64_t items = free_shape(c).items_per_tile * ntiles;
         const bool plain = !sp.enabled && !ap.enabled && !d_outA && !d_outB && c->opt_fuse;
-        const bool wins = c->kc.cells ? (plain ? c->N * (int64_t)B >= 1200000 && B >= 32 : c->N * (int64_t)B >= 10000000)
-                                      : items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1);
+        // (an evaluation over cells costs 12-18 us whatever N and B are: always - the sampler's steps and the diagnostics
+        // included, so that a row has the same bits whichever entry point evaluates it)
+        const bool wins = c->kc.cells ? true : items >= 4 * 2 * (int64_t)std::max(c->num_cu, 1);
+        (void)plain;
         if (wins || shared_bins || c->opt_persistent == 2 || c->opt_free_st)
             return enqueue_free(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     }

@@ -203,11 +203,10 @@ def test_cells_equal_the_sum_over_sources(n, nf, B):
     a0, b0 = ctx.lnprob_pieces(th)
     lp0 = ctx.lnprob_batch(th)
     ctx.close()
+    assert fc["cell"] > 0, fc                                               # (the cells did run)
     if n >= 33000:
-        assert fc["cell"] > 0, fc                                           # (the cells did run)
         assert fc["cell"] < 0.2 * (B - 2) * n * 2, fc                       # ... and are far fewer than the sources
-    else:
-        assert fc["cell"] == 0, fc                                          # (750 sources per field: under four per cell, no cells)
+    # (750 sources per field: under four per cell - a small catalogue gets its cells all the same, they beat the per-source path's overhead)
     assert np.array_equal(np.isinf(lp1), np.isinf(lp0)) and not np.isnan(lp1).any()
     assert np.isinf(lp1[1]) and np.isinf(lp1[2])
     fin = np.isfinite(lp0)
