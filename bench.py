@@ -59,6 +59,8 @@ def isa_counts(launch, variant):
     vi = {"free": 0, "fixcomp": 1, "zevol": 2}[variant]
     if launch.get("kind") == 2:                                       # (capi: the fused form reports kind 2 and "fused")
         key = "lf_free<%d>" % launch["st"]
+    elif launch.get("kind") == 4:                                     # the persistent kernel of the other two variants
+        key = "lf_pers<%d>" % vi
     else:
         key = "lf_main<%d,%d,%d,%d,%s>" % (vi, launch["st"], launch["tw"], launch["twb"], "true" if launch["compressed"] else "false")
     forms = doc["kernels"].get(key, {})
@@ -223,7 +225,9 @@ class Leg(object):
             self.rows_local, self.row_lo = self.half, 0
             self.grid_share = (rank, world)
         else:
-            self.ctx = model.context()
+            t0 = time.perf_counter()
+            self.ctx = model.context()          # lf_create: the flux sort, the cells, the proven grid bins, the tables' upload
+            self.create_s = time.perf_counter() - t0
             self.own_ctx = False
             self.ev = ShardedLnProb(self.ctx.lnprob_torch, self.ctx.ndim, dev, force_collective=args.force_collective)
             self.ki = ki
@@ -248,6 +252,8 @@ class Leg(object):
             ctx.set_option("cells", 0)
         if args.no_fuse:
             ctx.set_option("fuse", 0)
+        if args.no_grid_shortcut:
+            ctx.set_option("grid_shortcut", 0)
         self.ndim = ctx.ndim
         # global half-ensemble blocks, identical on every rank; 4 distinct steps' worth, cycled
         self.theta_all = synth.walkers(args.variant, self.half * nblk, seed=seed).reshape(nblk, self.half, self.ndim)
@@ -341,9 +347,36 @@ def census(leg, used):
     return {k: v / float(len(used)) for k, v in counts.items()}
 
 
+def grid_rows_per_bin(model):
+    """Mean number of luminosity rows that cross a flux bin of piece B (free variant, lf_gridbound.h): the length of the dot
+    product a bin's lane makes with the rows' Schechter values.  Recomputed on the host from the model's own grid."""
+    from lumfuncmcmc_amd import capi
+    ki = model.kernel_inputs()
+    logL, zarr = np.asarray(ki["logL"]), np.asarray(ki["zarr"])
+    S = logL.shape[0]
+    if not np.all(logL == logL[:, :1]):
+        return None
+    L = logL[:, 0]
+    wL = np.gradient(L) * 1.0
+    wL[0], wL[-1] = 0.5 * (L[1] - L[0]), 0.5 * (L[-1] - L[-2])
+    wz = np.gradient(zarr)
+    wz[0], wz[-1] = 0.5 * (zarr[1] - zarr[0]), 0.5 * (zarr[-1] - zarr[-2])
+    Dk = np.log10(4.0 * np.pi * (capi.MPC_CM * np.asarray(ki["DL_zarr"])) ** 2)
+    fcmin = float(ki.get("fcmin", 0.1))
+    fr = abs((2 * fcmin - 1) ** 2 / (1 - (2 * fcmin - 1) ** 2))
+    try:
+        g = capi.grid_bins([fr, ki["lims"]["alpha"][0], ki["lims"]["alpha"][1], ki["lims"]["Flim"][0], ki["lims"]["Flim"][1]],
+                           L, wL, wz * np.asarray(ki["volume_part"]), Dk)
+    except RuntimeError:
+        return None
+    return float(np.mean(g["rows"][:, 1])), int(g["rows"].shape[0])
+
+
 def roofline_of(args, leg, model, kt, dt):
-    """fp64-VALU roofline of the dominant kernel (lf_main: per-source sum + grid integral in one launch) on THIS rank:
-    executed flops of its share of the work / its average launch duration (HIP events on the launch stream)."""
+    """fp64-VALU roofline of the dominant kernel on THIS rank: EXECUTED flops of its share of the work / its average launch
+    duration (HIP events on the launch stream).  Executed flops = how many items took which form of the arithmetic (the
+    kernel's census, or - the persistent kernel of the other two variants - the chunk counts of its launch) x the flops of
+    that form in the compiler's assembly of the same sources (profiles/isa_counts.json)."""
     variant = args.variant
     k = kt["main"]
     launches = max(k["launches"], 1)
@@ -353,38 +386,60 @@ def roofline_of(args, leg, model, kt, dt):
     used = sorted({(2 * i) % leg.nblk for i in range(args.steps)} | {(2 * i + 1) % leg.nblk for i in range(args.steps)})
     launch = leg.ctx.last_launch()
     kernel, forms = isa_counts(launch, variant)
-    cnt = census(leg, used) if variant in ("free", "zevol") else {}
-    if variant == "zevol":
-        # the z-evolving kernel's census: "cell" = (walker, cell in redshift) pairs, "table" = terms of the local form (one
-        # exponential per lane of z-neighbours), "general" = per-source exponentials, "node_general" = grid nodes
+    zero = {"flops_per_item": 0.0, "cycles_per_item": 0.0}
+    per = lambda f: forms.get(f, zero)
+    cnt, extra = {}, {}
+    if launch["kind"] == 4:
+        # lf_pers: every walker inside the prior is summed over the cells in redshift (z-evolving) and integrates every node
+        # of the grid (64 per chunk, pads weigh 0); piece A of the fixed-completeness variant is a closed form
+        cnt = {"pzcell": 64.0 * launch["chunks_a"] * rows, "pznode": 64.0 * launch["chunks_b"] * rows}
+        src_flops, src_cycles = cnt["pzcell"] * per("pzcell")["flops_per_item"], cnt["pzcell"] * per("pzcell")["cycles_per_item"]
+        grid_flops, grid_cycles = cnt["pznode"] * per("pznode")["flops_per_item"], cnt["pznode"] * per("pznode")["cycles_per_item"]
+    elif variant == "zevol":
+        cnt = census(leg, used)
+        # lf_main's census: "cell" = (walker, cell in redshift) pairs, "table" = terms of the local form (one exponential per
+        # lane of z-neighbours), "general" = per-source exponentials, "node_general" = grid nodes
         name = {"cell": "zcell", "table": "zevol", "general": "zevol_direct", "node_general": "znode"}
-        zero = {"flops_per_item": 0.0, "cycles_per_item": 0.0}
-        src_flops = sum(cnt.get(f, 0.0) * forms.get(name[f], zero)["flops_per_item"] for f in ("cell", "table", "general"))
-        src_cycles = sum(cnt.get(f, 0.0) * forms.get(name[f], zero)["cycles_per_item"] for f in ("cell", "table", "general"))
-        grid_flops = cnt.get("node_general", 0.0) * forms.get("znode", zero)["flops_per_item"]
-        grid_cycles = cnt.get("node_general", 0.0) * forms.get("znode", zero)["cycles_per_item"]
+        src_flops = sum(cnt.get(f, 0.0) * per(name[f])["flops_per_item"] for f in ("cell", "table", "general"))
+        src_cycles = sum(cnt.get(f, 0.0) * per(name[f])["cycles_per_item"] for f in ("cell", "table", "general"))
+        grid_flops = cnt.get("node_general", 0.0) * per("znode")["flops_per_item"]
+        grid_cycles = cnt.get("node_general", 0.0) * per("znode")["cycles_per_item"]
     elif variant == "free":
-        src_flops = sum(cnt.get(f, 0.0) * forms[f]["flops_per_item"] for f in SOURCE_FORMS if f in forms)
-        src_cycles = sum(cnt.get(f, 0.0) * forms[f]["cycles_per_item"] for f in SOURCE_FORMS if f in forms)
-        grid_flops = sum(cnt.get(f, 0.0) * forms[f]["flops_per_item"] for f in NODE_FORMS if f in forms)
-        grid_cycles = sum(cnt.get(f, 0.0) * forms[f]["cycles_per_item"] for f in NODE_FORMS if f in forms)
+        cnt = census(leg, used)
+        src_flops = sum(cnt.get(f, 0.0) * per(f)["flops_per_item"] for f in SOURCE_FORMS)
+        src_cycles = sum(cnt.get(f, 0.0) * per(f)["cycles_per_item"] for f in SOURCE_FORMS)
+        grid_flops = sum(cnt.get(f, 0.0) * per(f)["flops_per_item"] for f in NODE_FORMS)
+        grid_cycles = sum(cnt.get(f, 0.0) * per(f)["cycles_per_item"] for f in NODE_FORMS)
+        rb = grid_rows_per_bin(model) if launch["kind"] == 2 and launch["chunks_b"] <= 64 else None
+        if rb is not None:
+            # piece B over flux bins: per (walker, bin, lane) besides the node's completeness sum (census: node_*) one
+            # Schechter value (an exponential: "qT") and a dot product over the rows that cross the bin (2 flops per row)
+            lanes = (cnt.get("node_general", 0.0) + cnt.get("node_bright", 0.0)) / max(leg.ctx.nf, 1)
+            extra = {"bin_lanes": lanes, "rows_per_bin": rb[0], "bins": rb[1]}
+            grid_flops += lanes * (per("qT")["flops_per_item"] + 2.0 * rb[0])
+            grid_cycles += lanes * (per("qT")["cycles_per_item"] + 4.0 * rb[0])
     else:
-        per = forms.get(variant, {"flops_per_item": 0.0, "cycles_per_item": 0.0})
-        src_flops, src_cycles = terms * per["flops_per_item"], terms * per["cycles_per_item"]
-        grid_flops = grid_cycles = 0.0
+        # fixed completeness in lf_main: piece A is a closed form, the grid costs one exponential per node
+        nodes = float(launch["chunks_b"]) * 256.0 * rows
+        cnt = {"fixnode": nodes}
+        src_flops = src_cycles = 0.0
+        grid_flops, grid_cycles = nodes * per("fixnode")["flops_per_item"], nodes * per("fixnode")["cycles_per_item"]
     alg_flops = src_flops + grid_flops
     alg_bytes = nsrc * BYTES_PER_SOURCE[variant] + rows * 8 * (leg.ndim + 1)
-    if cnt.get("cell", 0.0) > 0.0 and cnt.get("table", 0.0) + cnt.get("general", 0.0) == 0.0:
-        # every walker was summed over the catalogue's cells: 64 B per cell are streamed, not the sources
-        # (records of 80 B, free completeness: midpoint + 9 power sums; 64 B, z-evolving: midpoint + 7) - plus the grid's
-        # nodes, read once per launch: 64-B records (free) or five arrays of doubles (z-evolving)
-        nodes = cnt.get("node_general", 0.0) + cnt.get("node_bright", 0.0)
-        nodes = nodes / max(rows, 1) / (leg.ctx.nf if variant == "free" else 1)
-        alg_bytes = cnt["cell"] / max(rows, 1) * (80 if variant == "free" else 64) + nodes * (64 if variant == "free" else 40) \
-            + rows * 8 * (leg.ndim + 1)
+    on_cells = cnt.get("cell", 0.0) > 0.0 and cnt.get("table", 0.0) + cnt.get("general", 0.0) == 0.0
+    if on_cells or launch["kind"] == 4:
+        # every walker was summed over the catalogue's cells (or, fixed completeness, in closed form): what a launch streams
+        # is the cells' records (80 B free, 64 B z-evolving) and the grid's nodes / bins' nodes, once
+        if launch["kind"] == 4:
+            alg_bytes = 64.0 * launch["chunks_a"] * 64 + 64.0 * launch["chunks_b"] * 32 + rows * 8 * (leg.ndim + 1)
+        else:
+            nodes = (cnt.get("node_general", 0.0) + cnt.get("node_bright", 0.0)) / max(rows, 1) / (leg.ctx.nf if variant == "free" else 1)
+            alg_bytes = cnt["cell"] / max(rows, 1) * (80 if variant == "free" else 64) + nodes * (64 if variant == "free" else 40) \
+                + rows * 8 * (leg.ndim + 1)
     traffic = rocprof_ms = None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tf) and leg.world == 1 and not (args.no_cells or args.no_fuse or args.no_tables or args.no_specialise or args.compress):
+    ab = [n for n in AB_FLAGS if getattr(args, n)]
+    if os.path.exists(tf) and leg.world == 1 and not ab:
         try:
             ent = json.load(open(tf)).get("%s_n%d_b%d" % (variant, nsrc, rows), {})
             traffic = ent.get("hbm_bytes_per_launch")
@@ -395,26 +450,86 @@ def roofline_of(args, leg, model, kt, dt):
             traffic = rocprof_ms = None
     ach_tf = alg_flops / (avg_ms * 1e-3) / 1e12
     ach_gb = alg_bytes / (avg_ms * 1e-3) / 1e9
+    nominal = None
+    if variant == "free":
+        # SURVEY.md section 8d's NOMINAL count (every (walker, source) term at 226 flops, every node-field term at 228 + ...):
+        # what the reference's formulas would cost evaluated term by term - the kernel does not do that work (closed-form
+        # Schechter sum, cells, flux bins), so this figure is not a rate of anything executed
+        S = leg.ctx.S
+        nominal = rows * (nsrc * 226.0 + S * S * (46.0 + leg.ctx.nf * 182.0)) / (avg_ms * 1e-3) / 1e12
+    note = None
+    if on_cells or launch["kind"] == 4:
+        note = ("frac prices EXECUTED fp64 flops (census / chunk counts x the ISA's flops per item) against the vector-fp64 peak.  "
+                "The launch is a latency chain, not a stream of arithmetic: kernel arguments and theta from a cold cache, the "
+                "walkers' preparation, a few chunks of cells and grid per wave, the write-through of the partial sums, a counter, "
+                "the last workgroup's sums (tools/stamps_fused.py, profiles/*stamps*): frac says how little of the launch is "
+                "arithmetic, not how well the arithmetic runs." +
+                (("  SURVEY section 8d's NOMINAL count (226 flops per (walker, source) term, 228 per node-field term) would read "
+                  "%.0f TFLOP/s = %.1f x the peak here: the kernel does not do that work - closed-form Schechter sum, cells (a "
+                  "run of flux-neighbouring sources summed from 10 numbers), piece B over 64-node flux bins with a proven bound - "
+                  "and the parity tests against the reference's own lnprob are the proof that the result is the same.  The "
+                  "per-source kernel that does evaluate every term is in per_source_kernel." % (nominal, nominal / FP64_VALU_PEAK_TFLOPS))
+                 if nominal else ""))
     return {"bound": "valu_fp64", "kernel": kernel, "achieved": ach_tf,
             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_VALU_PEAK_TFLOPS,
             "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches, "rocprofv3_avg_launch_ms": rocprof_ms,
+            "traffic_and_rocprofv3_from": "profiles/hbm_traffic.json (the committed rocprofv3 passes of this command; not measured by this run)"
+            if traffic is not None else None,
             "launches_timed": "every %d-th of the timed region's %d, HIP events on the launch stream" % (max(args.profile_every, 1), 2 * args.steps),
             "measured_on": "rank 0",
             "launch": launch, "terms_per_launch": terms,
             "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
-            "items_per_launch_by_form": cnt,
+            "items_per_launch_by_form": cnt, "flux_bins": extra or None,
             "flops_per_item_by_form": {f: forms[f]["flops_per_item"] for f in forms},
             "cycles_per_item_by_form": {f: forms[f]["cycles_per_item"] for f in forms},
+            "nominal_survey_8d_tflops": nominal,
             "terms_per_s": terms / (avg_ms * 1e-3),
             # fraction of the 1024 SIMDs' issue cycles (at the 2.4 GHz spec clock) the counted forms need
             "valu_issue_frac_at_2p4GHz": (src_cycles + grid_cycles) / 64.0 / (avg_ms * 1e-3) / (1024 * 2.4e9),
             "hbm": {"bound": "hbm", "achieved": ach_gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach_gb / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
             "kernel_ms": {n: v["ms"] / max(v["launches"], 1) for n, v in kt.items() if n != "unused"},
-            "note": ("frac prices EXECUTED fp64 flops (census x ISA counts) against the vector-fp64 peak. Walkers summed over the "
-                     "catalogue's cells execute ~11x fewer flops per launch than the per-source kernel (--no-cells: frac 0.43) in "
-                     "~4x less time, so frac falls while evals/s rises; the launch is ~0.6 VALU-busy over its whole length "
-                     "(profiles/*_pmc.json), the rest is dispatch, table load, walker preparation and the final sums") if cnt.get("cell", 0.0) > 0.0 else None}
+            "note": note}
+
+
+AB_FLAGS = ("no_cells", "no_fuse", "no_tables", "no_specialise", "no_grid_shortcut", "compress", "taper")
+# BASELINE.json's configurations as presets: variant, sources, walkers in all, scaling ("config 1" is the reference's CPU case:
+# its shape runs here on the GPU)
+CONFIGS = {1: ("free", 1000, 32, "weak"), 2: ("free", 100000, 256, "weak"), 3: ("free", 1000000, 512, "weak"),
+           4: ("free", 1000000, 1024, "strong"), 5: ("zevol", 800000, 512, "strong")}
+
+
+def host_cost(leg, burst=64, reps=40):
+    """Host time of one evaluation call (Python -> ctypes -> hipLaunchKernel), apart from the queue's back-pressure: bursts of
+    `burst` calls on an idle stream; and the same evaluations enqueued by ONE call of the C loop (lf_lnprob_batch_device_n)."""
+    import gc
+    import torch
+    ctx = leg.ctx
+    th = leg.blocks[0][leg.row_lo:leg.row_lo + leg.rows_local].contiguous()
+    out = torch.empty(th.shape[0], dtype=torch.float64, device=th.device)
+    ring = th.unsqueeze(0).repeat(burst, 1, 1).contiguous()
+    out_n = torch.empty((burst, th.shape[0]), dtype=torch.float64, device=th.device)
+    res = {}
+    gc.collect()
+    gc.disable()
+    for name, call, per in (("python_per_call", lambda: [ctx.lnprob_torch(th, out=out) for _ in range(burst)], burst),
+                            ("c_loop_per_evaluation", lambda: ctx.lnprob_torch_n(ring, out=out_n), burst)):
+        host, total = [], []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            call()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            host.append(1e6 * (t1 - t0) / per)
+            total.append(1e6 * (t2 - t0) / per)
+        res[name] = {"host_us": float(np.median(host[3:])), "enqueue_plus_device_us": float(np.median(total[3:]))}
+    gc.enable()
+    res["burst"] = burst
+    res["note"] = ("host_us: median over bursts of %d evaluations enqueued on an idle stream (the queue never fills: no "
+                   "back-pressure in the figure); enqueue_plus_device_us: the same bursts up to the device's completion" % burst)
+    return res
 
 
 def main():
@@ -440,6 +555,10 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="A/B: three launches per evaluation (lf_prepare, lf_free, lf_finalize) instead of one")
     ap.add_argument("--no-cells", action="store_true", help="A/B: every walker summed over the sources, not over the catalogue's cells")
     ap.add_argument("--no-tables", action="store_true", help="A/B: the general form of the free term only (no g/h tables)")
+    ap.add_argument("--no-grid-shortcut", action="store_true",
+                    help="A/B: piece B of the free variant over the S^2 lattice points instead of the proven flux bins")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="BASELINE.json's configuration 1-5 as a preset of --variant / --nsrc / --walkers / --scaling (0: the metric's workload)")
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")
@@ -447,9 +566,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
-    ap.add_argument("--profile-every", type=int, default=8,
+    ap.add_argument("--profile-every", type=int, default=10,
                     help="bracket only every n-th evaluation of the timed steps with events (each pair stalls the stream ~8 us)")
     args = ap.parse_args()
+    if args.config:
+        args.variant, args.nsrc, wtot, args.scaling = CONFIGS[args.config]
+        args.walkers = wtot if args.scaling == "strong" else wtot      # (weak presets are 1-GPU shapes: walkers per GPU = in all)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -488,7 +610,9 @@ def main():
     Wtot = W * world if scaling == "weak" else W
     if Wtot % 2 or Wtot < 2:
         raise SystemExit("the ensemble needs an even number of walkers")
+    t_setup = time.perf_counter()
     model = build_model(args.variant, args.nsrc, Wtot, local)
+    host_setup_s = time.perf_counter() - t_setup
 
     def fence():
         if multi:
@@ -541,9 +665,16 @@ def main():
                           "walkers_total": Wtot, "variant": args.variant, "shard": shard if world > 1 else "none",
                           "parallelism": par},
                "roofline": roofline_of(args, leg, model, kt, dt)}
-    ab = [n for n in ("no_cells", "no_fuse", "no_tables", "no_specialise", "compress", "taper") if getattr(args, n)]
+    ab = [n for n in AB_FLAGS if getattr(args, n)]
     if ab and rank == 0:
         res["config"]["ab_options"] = ab                    # an A/B run, not the default path
+    if rank == 0:
+        if args.config:
+            res["config"]["baseline_config"] = args.config
+        # what precedes the first evaluation: the host setup of the class (cosmology tables, grids: NumPy / SciPy) and
+        # lf_create (flux sort, cells, proven grid bins, uploads) - once per run, not in `value`
+        res["setup_s"] = {"host_setup": host_setup_s, "lf_create": getattr(leg, "create_s", None),
+                          "note": "once per catalogue, before the timed region"}
     if world > 1 and scaling == "weak" and not args.no_extras:
         # the metric's literal shape - a FIXED ensemble of --walkers walkers - on the same GPUs, in the same run:
         # sharded by walker (all-gather) and by source (all-reduce)
@@ -587,6 +718,68 @@ def main():
                                           "note": "counts every proposal, as emcee does; proposals outside the prior box are "
                                                   "-inf without being evaluated (MODE_SKIP)"}
             ds.close()
+        if world == 1 and not args.no_extras:
+            try:
+                res["host"] = host_cost(leg)
+                res["host_us_per_call"] = res["host"]["python_per_call"]["host_us"]
+                # the timed workload again with its 2 x steps evaluations enqueued by ONE call of the C loop
+                import gc
+                K = 2 * args.steps
+                ring = torch.stack([leg.blocks[j % nblk][leg.row_lo:leg.row_lo + leg.rows_local] for j in range(K)]).contiguous()
+                out_n = torch.empty((K, leg.rows_local), dtype=torch.float64, device=dev)
+                for _ in range(3):
+                    ctx.lnprob_torch_n(ring, out=out_n)
+                fence()
+                gc.collect()
+                gc.disable()
+                t1 = time.perf_counter()
+                ctx.lnprob_torch_n(ring, out=out_n)
+                fence()
+                t2 = time.perf_counter() - t1
+                gc.enable()
+                res["k_calls_per_c_call"] = {"value": W * args.steps / t2, "unit": "walker-lnprob evals/s", "ms_per_step": t2 / args.steps * 1e3,
+                                             "evaluations_per_c_call": K,
+                                             "note": "the same %d steps, their evaluations enqueued by one lf_lnprob_batch_device_n call "
+                                                     "instead of %d calls from Python" % (args.steps, K)}
+            except Exception as e:                 # an extra figure: never at the cost of the bench line
+                res["host"] = {"error": repr(e)}
+        if world == 1 and not args.no_extras and args.variant == "free" and not ab and leg.ctx.last_launch()["kind"] == 2:
+            # The kernel north_star literally describes - every (walker, source) term evaluated, the catalogue streamed - is
+            # what serves walkers that cannot be summed over the cells; timed here on the same workload with the cells off.
+            try:
+                ctx.set_option("cells", 0)
+                nst = max(10, args.steps)
+                saved = args.steps
+                args.steps = nst
+                d3, kt3, _ = timed(leg, fence, 2, nst, 1, profile_every=4)
+                setattr(args, "no_cells", True)
+                r3 = roofline_of(args, leg, model, kt3, d3)
+                setattr(args, "no_cells", False)
+                args.steps = saved
+                ent = {}
+                try:
+                    ent = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(
+                        "free_n%d_b%d_nocells" % (leg.ctx.N, leg.rows_local), {})
+                except Exception:
+                    pass
+                hb = ent.get("hbm_bytes_per_launch")
+                res["per_source_kernel"] = {
+                    "value": W * nst / d3, "unit": "walker-lnprob evals/s", "ms_per_step": d3 / nst * 1e3, "steps": nst,
+                    "kernel": r3["kernel"], "avg_launch_ms": r3["avg_launch_ms"], "launches": r3["launches"],
+                    "executed_tflops": r3["achieved"], "frac_of_fp64_peak": r3["frac"],
+                    "items_per_launch_by_form": r3["items_per_launch_by_form"],
+                    "algorithmic_bytes_per_launch": r3["hbm"]["algorithmic_bytes_per_launch"],
+                    "algorithmic_gb_per_s": r3["hbm"]["achieved"], "hbm_peak_gb_per_s": HBM_PEAK_GBS,
+                    "hbm_bytes_per_launch_pmc": hb,
+                    "hbm_gb_per_s_pmc": (hb / (r3["avg_launch_ms"] * 1e-3) / 1e9) if hb else None,
+                    "note": "option cells = 0: every walker over the sources (lf_free's table-driven per-source path: "
+                            "the catalogue's log-flux streamed by 8-byte loads, 8 B per source and launch); compute-bound on fp64 "
+                            "VALU issue by design - the HBM rate is a few per cent of the peak (pmc figures: the committed "
+                            "rocprofv3 passes in profiles/hbm_traffic.json)"}
+            except Exception as e:
+                res["per_source_kernel"] = {"error": repr(e)}
+            finally:
+                ctx.set_option("cells", 1)
         if world == 1 and not args.compress and not args.no_extras:
             # separately labelled, NOT the headline: the same workload with piece A taken from the compressed
             # catalogue (opt-in "compress" option, csrc/lf_compress.h) - the roofline above is the direct kernel's

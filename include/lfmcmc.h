@@ -115,6 +115,13 @@ int lf_lnprob_batch(lf_ctx *ctx, const double *theta, int B, double *out);
  * lnprob feeds the RCCL all-gather without a host round trip). */
 int lf_lnprob_batch_device(lf_ctx *ctx, const double *d_theta, int B, double *d_out, void *hip_stream);
 
+/* K evaluations in one call: block k is theta rows d_theta[k B ndim ..] -> d_out[k B ..], k = 0 .. K-1, enqueued back to back
+ * on `hip_stream` (what K calls of lf_lnprob_batch_device enqueue, without K trips through the caller's language: a Python
+ * caller spends 7 us per call, this loop 2-3 us per evaluation; the evaluations themselves take 8-21 us each).  For callers
+ * with many independent half-ensembles to evaluate (several chains, a tempering ladder); emcee's stretch move itself
+ * (lumfuncmcmc.py:489-491) needs block k's result before it can propose block k + 1 - that loop is lf_sampler_run's. */
+int lf_lnprob_batch_device_n(lf_ctx *ctx, const double *d_theta, int B, int K, double *d_out, void *hip_stream);
+
 /* Diagnostics for parity tests: the two pieces of lnlike separately (host buffers).
  * outA[i] = per-source log-term sum (lumfuncmcmc.py:370 / :388 / lumfuncmcmc_z.py:371),
  * outB[i] = expected-count integral (:373-377 / :389-392 / _z:373-375).  Rows failing the prior

@@ -40,7 +40,7 @@ class LfDesc(ctypes.Structure):
 
 
 EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_batch",
-           "lf_lnprob_batch_device", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
+           "lf_lnprob_batch_device", "lf_lnprob_batch_device_n", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
            "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_grid_bins", "lf_form_counts", "lf_last_launch", "lf_veff")
@@ -82,6 +82,9 @@ def load():
     lib.lf_lnprob_batch_device.restype = ctypes.c_int
     lib.lf_lnprob_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_void_p]
+    lib.lf_lnprob_batch_device_n.restype = ctypes.c_int
+    lib.lf_lnprob_batch_device_n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_void_p]
     lib.lf_lnprob_pieces.restype = ctypes.c_int
     lib.lf_lnprob_pieces.argtypes = [ctypes.c_void_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]
     lib.lf_set_profiling.restype = ctypes.c_int
@@ -361,6 +364,21 @@ class LFContext(object):
         if B:
             stream = torch.cuda.current_stream(theta.device).cuda_stream
             self.lnprob_batch_device(theta.data_ptr(), B, out.data_ptr(), stream)
+        return out
+
+    def lnprob_torch_n(self, theta, out=None):
+        """K independent blocks in one C call (lf_lnprob_batch_device_n): theta (K, B, ndim) device tensor -> (K, B)."""
+        import torch
+        if theta.dtype != torch.float64 or not theta.is_cuda or theta.dim() != 3 or theta.shape[2] != self.ndim:
+            raise ValueError("theta must be a float64 device tensor of shape (K, B, %d)" % self.ndim)
+        theta = theta.contiguous()
+        K, B = theta.shape[0], theta.shape[1]
+        if out is None:
+            out = torch.empty((K, B), dtype=torch.float64, device=theta.device)
+        if K and B:
+            stream = torch.cuda.current_stream(theta.device).cuda_stream
+            self._check(self._lib.lf_lnprob_batch_device_n(self._h, ctypes.c_void_p(theta.data_ptr()), int(B), int(K),
+                                                           ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
         return out
 
     def set_profiling(self, level):

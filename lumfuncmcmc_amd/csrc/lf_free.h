@@ -407,7 +407,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                         double o[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) o[i] = i < nr ? om[i * 64] : 0.0;
+                        asm volatile("; LF_BEGIN qT items=1");
                         Tl[lane] = fexp_c(fma(uni(sc[R_C1]), nd.L - uni(sc[R_LSTAR]), uni(sc[R_C0])) - nd.PGL * uni(sc[R_Q]), &tab);
+                        asm volatile("; LF_END qT");
                         // the bin's faintest node is its last (the nodes descend), for the bright form of the field sum
                         const double a4min = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nd.a4), 63),
                                                               __builtin_amdgcn_readlane(__double2loint(nd.a4), 63));

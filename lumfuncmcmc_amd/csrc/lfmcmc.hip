@@ -1565,6 +1565,21 @@ int lf_lnprob_batch_device(lf_ctx* c, const double* d_theta, int B, double* d_ou
     return enqueue(c, d_theta, B, d_out, nullptr, nullptr, (hipStream_t)hip_stream);
 }
 
+int lf_lnprob_batch_device_n(lf_ctx* c, const double* d_theta, int B, int K, double* d_out, void* hip_stream) {
+    if (!c) return LF_ERR_ARG;
+    if (!d_theta || !d_out || B <= 0 || K <= 0) {
+        c->err = "lf_lnprob_batch_device_n: NULL pointer, B <= 0 or K <= 0";
+        return LF_ERR_ARG;
+    }
+    LF_HIP(c, hipSetDevice(c->device));
+    const size_t nd = (size_t)c->kc.ndim;
+    for (int k = 0; k < K; ++k) {
+        const int rc = enqueue(c, d_theta + (size_t)k * B * nd, B, d_out + (size_t)k * B, nullptr, nullptr, (hipStream_t)hip_stream);
+        if (rc != LF_OK) return rc;
+    }
+    return LF_OK;
+}
+
 static int host_eval(lf_ctx* c, const double* theta, int B, double* out, double* outA, double* outB) {
     using namespace lf;
     if (!c) return LF_ERR_ARG;

@@ -446,7 +446,15 @@ class LumFuncMCMC(_Base):
         self._veff(sum_Omega, zmaxval, device)
 
     def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
-        raise NotImplementedError("triangle_plot needs corner/matplotlib; plotting is outside the scope of this build (use set_median_fit)")
+        """lumfuncmcmc.py:604-651.  The figure itself (corner + matplotlib) is outside the scope of this build; what the
+        drivers write AFTER it is not: with configLF's default output_dict they call this right after fit_model()
+        (run_lumfuncmcmc.py:291-293) and then read medianLF, Lavg, lfbinorig, var.  So everything the reference's
+        add_subplots computes on the way (:576-603: median LF over random posterior draws, median Flim / alpha, roots_ln,
+        VeffLF) is computed here, the skipped figure is logged, and the finished chain is kept."""
+        self.set_median_fit(lnprobcut=lnprobcut)
+        self.roots_ln = self.rootsf.ev(self.Flim, self.alpha)
+        self.log.warning("triangle_plot: %s.%s not drawn (plotting is outside the scope of this build); "
+                         "medianLF, Flim, alpha, roots_ln and the 1/Veff estimate are set as the figure's code would set them" % (outname, imgtype))
 
 
 class LumFuncMCMCz(_Base):
@@ -555,7 +563,7 @@ class LumFuncMCMCz(_Base):
         return vals
 
     def set_median_fit(self, lnprobcut=7.5, zlen=100, Llen=100):
-        """Median-parameter LF surface on a (z, L) mesh (lumfuncmcmc_z.py:480-513), without VeffLF."""
+        """Median-parameter LF surface on a (z, L) mesh, then the 1/Veff estimate (lumfuncmcmc_z.py:480-513)."""
         nsamples = self._select_samples(lnprobcut, keep_lnprob=False)
         self.Lout = np.linspace(min(self.lum) - 0.2, max(self.lum) + 0.2, Llen)
         self.zout = np.linspace(self.zmin, self.zmax, zlen)
@@ -576,4 +584,20 @@ class LumFuncMCMCz(_Base):
         self._veff(sum_Omega, zmaxval, device)
 
     def triangle_plot(self, outname, lnprobcut=7.5, imgtype='png'):
-        raise NotImplementedError("triangle_plot needs corner/matplotlib; plotting is outside the scope of this build (use set_median_fit)")
+        """lumfuncmcmc_z.py:546-585.  As for LumFuncMCMC.triangle_plot: the figure is out of scope, the numbers its code
+        leaves behind for the driver (run_lumfuncmcmc_z.py:264-281: Lout, zout, medianLF on the mesh of add_subplots
+        :524-533, VeffLF) are made, the skipped figure is logged."""
+        nsamples = self._select_samples(lnprobcut, keep_lnprob=True)
+        zlen = Llen = 100
+        self.Lout = np.linspace(min(self.lum) - 0.08, max(self.lum) + 0.01, Llen)
+        self.zout = np.linspace(self.zmin, self.zmax, zlen)
+        self.medianLF = np.zeros((zlen, Llen))
+        # (the reference takes the medians of nsamples WITH its lnprob column here and hands the list to
+        # set_parameters_from_list, which reads the leading entries only)
+        self.set_parameters_from_list(np.percentile(nsamples, 50.0, axis=0))
+        for i in np.arange(zlen):
+            self.medianLF[i] = schechter_z(self.Lout, self.zout[i], self.sch_al, self.L1, self.L2, self.L3,
+                                           self.phi1, self.phi2, self.phi3, self.z1, self.z2, self.z3)
+        self._veff_or_skip()
+        self.log.warning("triangle_plot: %s.%s not drawn (plotting is outside the scope of this build); "
+                         "Lout, zout, medianLF and the 1/Veff estimate are set as the figure's code would set them" % (outname, imgtype))

@@ -86,9 +86,12 @@ def analyse(s):
     for name, lines in kernels(s):
         m = re.search(r"lf_mainILi(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)", name)
         mf = re.search(r"lf_freeILi(\d+)ELb0ELb1E", name)     # the persistent FREE kernel, product (fused) instantiation
+        mp = re.search(r"lf_persILi(\d)ELb1E", name)           # the persistent kernel of the other two variants, one-launch form
         if mf:
             st = int(mf.group(1))
             key = "lf_free<%d>" % st
+        elif mp:
+            key = "lf_pers<%d>" % int(mp.group(1))
         elif m:
             variant, st, tw, twb, cmp_ = (int(x) for x in m.groups())
             key = "lf_main<%d,%d,%d,%d,%s>" % (variant, st, tw, twb, "true" if cmp_ else "false")

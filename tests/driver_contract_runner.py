@@ -1,5 +1,7 @@
 """Runs the REFERENCE's own driver, in place, over this package's classes (tests/test_driver_contract.py starts it
-under an interpreter that has astropy).  argv: <workdir> <reference dir> <nsources> <nwalkers> <nsteps> [-fc] [-fsa].
+under an interpreter that has astropy).  argv: <workdir> <reference dir> <nsources> <nwalkers> <nsteps> [--z] [--default-config]
+[-fc] [-fsa].  --z: run_lumfuncmcmc_z.py over LumFuncMCMCz instead of run_lumfuncmcmc.py over LumFuncMCMC; --default-config:
+configLF.output_dict as the reference ships it ('triangle plot': True), i.e. the driver with NO config edits.
 
 sys.path order: dropin/ (lumfuncmcmc, lumfuncmcmc_z, VmaxLumFunc resolve to this package), the repo, oracle/ and
 only then the reference checkout (run_lumfuncmcmc.py, configLF.py).  The GPU is not needed: `_Base._evaluate` is
@@ -14,6 +16,9 @@ import numpy as np
 
 work, ref, nsrc, nwalk, nsteps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 flags = sys.argv[6:]
+ZDRIVER = "--z" in flags
+DEFAULT_CONFIG = "--default-config" in flags
+flags = [f for f in flags if f not in ("--z", "--default-config")]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "dropin"), ROOT, os.path.join(ROOT, "oracle"), ref]
 
@@ -44,12 +49,23 @@ with open("combined_all_Swift_NoDust_Donley_removed.dat", "w") as fh:
 
 # ---- the reference's driver, imported where it lies
 import configLF                                        # noqa: E402
-import run_lumfuncmcmc as drv                          # noqa: E402
-assert drv.LumFuncMCMC is model.LumFuncMCMC, "the driver did not pick up the drop-in class"
+if ZDRIVER:
+    import run_lumfuncmcmc_z as drv                    # noqa: E402
+    assert drv.LumFuncMCMCz is model.LumFuncMCMCz, "the driver did not pick up the drop-in class"
+    cls, outdir = model.LumFuncMCMCz, "LFMCMCzOut"
+    # run_lumfuncmcmc_z.py:274-279 writes the (zlen, Llen) medianLF matrix as ONE table column next to two 1-d columns:
+    # astropy (4.3.1 here) refuses that in the REFERENCE's own code, whatever class produced the arrays - the one output the
+    # z driver cannot write in this container
+    configLF.output_dict["bestfitLF"] = False
+else:
+    import run_lumfuncmcmc as drv                      # noqa: E402
+    assert drv.LumFuncMCMC is model.LumFuncMCMC, "the driver did not pick up the drop-in class"
+    cls, outdir = model.LumFuncMCMC, "LFMCMCOut"
 assert os.path.dirname(os.path.abspath(drv.__file__)) == os.path.abspath(ref)
-configLF.output_dict["triangle plot"] = False          # plotting is outside the scope of this build
+if not DEFAULT_CONFIG:
+    configLF.output_dict["triangle plot"] = False      # (the other branch of the driver: set_median_fit)
 
-model.LumFuncMCMC.device_sampler = False               # host sampler: no GPU in this test
+cls.device_sampler = False                             # host sampler: no GPU in this test
 
 
 def evaluate(self, theta):                             # the oracle in place of liblfmcmc.so (tests only)
@@ -64,9 +80,9 @@ model._Base._evaluate = evaluate
 np.random.seed(12345)
 drv.main(["-f", "cat.dat", "-o", "contract.dat", "-nw", str(nwalk), "-ns", str(nsteps), "-nbins", "10", "-nboot", "20"] + flags)
 
-out = sorted(os.listdir("LFMCMCOut"))
+out = sorted(os.listdir(outdir))
 from astropy.table import Table                        # noqa: E402
 post = [f for f in out if f.startswith("fitposterior")][0]
-t = Table.read(os.path.join("LFMCMCOut", post), format="ascii.fixed_width_two_line")
+t = Table.read(os.path.join(outdir, post), format="ascii.fixed_width_two_line")
 print(json.dumps({"files": out, "posterior_columns": len(t.colnames), "posterior_rows": len(t),
                   "finite_lnprob": int(np.isfinite(np.asarray(t[t.colnames[-1]], dtype=float)).sum())}))

@@ -1,7 +1,8 @@
 """The drop-in claim, end to end: the REFERENCE's own CLI driver (run_lumfuncmcmc.py:230-330, imported in place from the
 reference checkout) runs over this package's LumFuncMCMC (dropin/lumfuncmcmc.py, dropin/VmaxLumFunc.py): constructor with
 the driver's keywords -> table -> fit_model -> set_median_fit -> samples / lum / lum_e / medianLF / Lavg / lfbinorig / var
--> add_fitinfo_to_table -> the five output files.  BASELINE config 1: 1k synthetic sources, 32 walkers, 50 steps.
+-> add_fitinfo_to_table -> the five output files; the same for run_lumfuncmcmc_z.py over LumFuncMCMCz; and both with configLF.output_dict as shipped
+('triangle plot': True).  BASELINE config 1: 1k synthetic sources, 32 walkers, 50 steps.
 
 Build container only: needs the reference checkout and an interpreter with astropy (the driver reads and writes astropy
 tables); skipped elsewhere.  No GPU: lnprob is served by the oracle here (tests/driver_contract_runner.py)."""
@@ -32,7 +33,13 @@ def _interpreter():
     return None
 
 
-@pytest.mark.parametrize("flags,ndim", [([], 9), (["-fc"], 3), (["-fsa"], 8)])
+@pytest.mark.parametrize("flags,ndim", [([], 9), (["-fc"], 3), (["-fsa"], 8),
+                                        # the drivers with NO config edits: configLF.output_dict as shipped asks for the
+                                        # triangle plot right after fit_model() (run_lumfuncmcmc.py:291-293) - the figure is
+                                        # out of scope, the finished chain and the outputs behind it are not
+                                        (["--default-config"], 9), (["--default-config", "-fc"], 3),
+                                        # run_lumfuncmcmc_z.py over LumFuncMCMCz (:205-303), both branches
+                                        (["--z"], 7), (["--z", "-fsa"], 6), (["--z", "--default-config"], 7)])
 def test_reference_driver_runs_on_the_dropin_classes(tmp_path, flags, ndim):
     if not os.path.exists(os.path.join(REF, "run_lumfuncmcmc.py")):
         pytest.skip("reference checkout not present (GPU box): the contract is exercised in the build container")
@@ -44,7 +51,8 @@ def test_reference_driver_runs_on_the_dropin_classes(tmp_path, flags, ndim):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     kinds = {f.split("_")[0] for f in res["files"]}
-    assert {"fitposterior", "bestfitLF", "VeffLF"} <= kinds, res           # run_lumfuncmcmc.py:298-311
+    want = {"fitposterior", "VeffLF"} if "--z" in flags else {"fitposterior", "bestfitLF", "VeffLF"}
+    assert want <= kinds, res                                              # run_lumfuncmcmc.py:298-311, _z:270-290
     assert "contract.dat" in res["files"] and "contract.dat.args" in res["files"]   # :317-330
     assert res["posterior_columns"] == ndim + 1                            # samples = chain + lnprob (lumfuncmcmc.py:506-510)
     assert res["posterior_rows"] >= 32 * 25                                # burn-in is at most nsteps // 2
