@@ -274,7 +274,8 @@ int64_t lf_grid_bins(const double *params, int S, const double *L, const double 
  *   (pref0 = sum(Omega_0) / sqarcsec; fcmin <= 0 = the unmodified Fleming curve);
  *   sums[(nboot + 1) * nbin]: row 0 = sum of phi per luminosity bin (bin_of[i] in [0, nbin), anything else = no bin),
  *   rows 1..nboot = the same over bootstrap resamples of the catalogue: indices from boot_idx[nboot * n] when given
- *   (a caller replaying a seeded host stream), else drawn on the device (Philox4x32-10 keyed by seed).
+ *   (a caller replaying a seeded host stream; every index must lie in [0, n): LF_ERR_ARG otherwise), else drawn on the
+ *   device (Philox4x32-10 keyed by seed).
  * nbin = 0 skips the binning (bin_of, sums may be NULL).  nbin <= 1024.  Synchronous. */
 int lf_veff(int device, int64_t n, const double *flux, const double *flim, const double *vol, double vol_all, double pref0,
             double alpha, double fcmin, const int32_t *bin_of, int32_t nbin, int32_t nboot, const int64_t *boot_idx, uint64_t seed,

@@ -1681,6 +1681,10 @@ int lf_veff(int device, int64_t n, const double* flux, const double* flim, const
             double* phi, double* sums) {
     if (n <= 0 || !flux || !flim || !phi || pref0 <= 0.0 || nbin < 0 || nbin > lf::VEFF_MAXBIN || nboot < 0 || (nbin > 0 && (!bin_of || !sums)))
         return LF_ERR_ARG;
+    // the caller's resampling indices address phi and bin_of on the device: outside [0, n) they are refused here
+    if (boot_idx && nbin > 0)
+        for (int64_t i = 0; i < n * (int64_t)nboot; ++i)
+            if (boot_idx[i] < 0 || boot_idx[i] >= n) return LF_ERR_ARG;
     if (hipSetDevice(device) != hipSuccess) return LF_ERR_NODEV;
     double *d_flux = nullptr, *d_flim = nullptr, *d_vol = nullptr, *d_phi = nullptr, *d_sums = nullptr;
     int* d_bin = nullptr;

@@ -192,6 +192,17 @@ class _Base(object):
             out = np.asarray(self.lnprob_fn(np.atleast_2d(th)))
         else:
             out = self.context().lnprob_batch(th)
+            rank, world = self._dist_state()
+            if self.shard == "sources" and world > 1:
+                # this rank's context holds 1/world of every field's sources and of the grid: its lnprob is a partial sum -
+                # the ranks' sum is the value (every rank calls this with the same theta, as every collective requires)
+                import torch
+                import torch.distributed as tdist
+                t = torch.from_numpy(np.ascontiguousarray(np.atleast_1d(out), dtype=np.float64))
+                if tdist.get_backend() == "nccl":
+                    t = t.to("cuda:%d" % self.device)
+                tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+                out = t.cpu().numpy()
         return float(out[0]) if scalar else out
 
     # ------------------------------------------------------------------ sampling

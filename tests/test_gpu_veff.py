@@ -67,3 +67,19 @@ def test_device_veff_against_the_host_at_catalogue_size():
     ratio = o.var[ok] / host[2][ok]
     assert 0.5 < np.median(ratio) < 2.0 and np.all(ratio > 0.1) and np.all(ratio < 10.0), ratio
     o.close()
+
+
+def test_resampling_indices_outside_the_catalogue_are_refused():
+    """boot_idx addresses the weights on the device: an index outside [0, n) is an argument error, not a stray read"""
+    from lumfuncmcmc_amd import capi
+    n = 1000
+    rng = np.random.default_rng(1)
+    flux, flim = rng.uniform(2e-17, 9e-17, n), np.full(n, 2.7e-17)
+    bins = rng.integers(0, 10, n)
+    for bad in (-1, n, 2 ** 40):
+        idx = rng.integers(0, n, (3, n))
+        idx[1, 17] = bad
+        with pytest.raises(capi.LFError):
+            capi.veff_device(flux, flim, 1.0e6, 0.04, 4.56, 0.1, bin_of=bins, nbin=10, nboot=3, boot_idx=idx)
+    phi, sums = capi.veff_device(flux, flim, 1.0e6, 0.04, 4.56, 0.1, bin_of=bins, nbin=10, nboot=3, boot_idx=rng.integers(0, n, (3, n)))
+    assert np.isfinite(phi).all() and sums.shape == (4, 10)

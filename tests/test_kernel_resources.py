@@ -58,6 +58,76 @@ def test_persistent_free_kernel_fits_four_waves_per_simd_without_scratch(remarks
             assert r["LDS Size"] <= 80 * 1024, (name, r)      # two workgroups per CU (160 KB)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_persistent_kernel_of_the_other_variants_fits_two_workgroups_per_cu(remarks, variant):
+    for fused in (0, 1):
+        for name, r in _find(remarks, "_ZN2lf7lf_persILi%dELb%dEEE" % (variant, fused)).items():
+            assert r["VGPRs"] <= 128 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
+            assert r["LDS Size"] <= 80 * 1024, (name, r)
+
+
 def test_big_geometry_of_lf_main_has_no_scratch(remarks):
     for name, r in _find(remarks, "_ZN2lf7lf_mainILi0ELi8ELi16ELi16ELb0EEE").items():
         assert r["ScratchSize"] == 0 and r["VGPRs"] <= 128, (name, r)
+
+
+# ---------------------------------------------------------------------------------------------- the one-launch form's ISA
+@pytest.fixture(scope="module")
+def asm():
+    hipcc = build.hipcc()
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "lf.s")
+        r = subprocess.run([hipcc] + build.CXXFLAGS + ["--cuda-device-only", "-S", "-o", out, SRC], stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        text = open(out).read()
+    kern = {}
+    for m in re.finditer(r"^(_ZN2lf\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        kern[m.group(1)] = [l.strip() for l in m.group(2).split("\n")]
+    return kern
+
+
+def _instr(lines):
+    """instruction lines only (no labels, comments, directives, asm-block markers)"""
+    return [l for l in lines if l and not l.startswith((";", ".", "//")) and not l.endswith(":")]
+
+
+FUSED = [("_ZN2lf7lf_freeILi%dELb0ELb1EEE" % st) for st in (2, 4, 8)] + ["_ZN2lf7lf_persILi1ELb1EEE", "_ZN2lf7lf_persILi2ELb1EEE"]
+
+
+@pytest.mark.parametrize("prefix", FUSED)
+def test_one_launch_form_hands_its_partial_sums_over_through_memory(asm, prefix):
+    """The hand-over between the workgroups of a tile (lf_free.h / lf_pers.h, FUSED) rests on four facts
+    of the generated code, pinned here so that a compiler change cannot silently remove one:
+      1. every partial sum is stored with the agent-scope cache policy (sc1: written through this XCD's L2);
+      2. each wave waits for its stores' acknowledgements (s_waitcnt vmcnt(0)) directly in front of the workgroup barrier
+         that precedes the count;
+      3. the count is ONE returning global atomic add of the constant 1 by one lane (not a wave-aggregated add, whose
+         result the atomic optimizer would read where it is issued) - and the only atomic behind that barrier;
+      4. the finishing workgroup reads the partial sums with the same cache policy (sc1: past its own L2's stale lines)."""
+    names = [k for k in asm if k.startswith(prefix)]
+    assert len(names) == 1, names
+    ins = _instr(asm[names[0]])
+    stores = [l for l in ins if l.startswith("global_store_dwordx2")]
+    sc1_stores = [l for l in stores if l.endswith(" sc1")]
+    # (the kernel's only 8-byte stores to memory are the partial sums, written through, and lnprob itself)
+    assert len(sc1_stores) >= 2 and len(stores) - len(sc1_stores) <= 1, stores
+    assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in ins), "a cache-wide write-back / invalidate crept in (154 us per evaluation)"
+    # the count: wait - barrier - one-lane returning atomic - barrier
+    at = [i for i, l in enumerate(ins) if l.startswith("global_atomic_add") and l.endswith(" sc0") and "offset" not in l]
+    assert len(at) == 1, [ins[i] for i in at]            # (the queue claims of lf_free's source path carry an offset)
+    i = at[0]
+    before = ins[max(0, i - 40):i]
+    bar = max(j for j, l in enumerate(before) if l == "s_barrier")
+    w = max((j for j, l in enumerate(before[:bar]) if l == "s_waitcnt vmcnt(0)"), default=-1)
+    # (scalar bookkeeping may sit between the wait and the barrier; no memory instruction may)
+    assert w >= 0 and bar - w <= 10 and not any(l.startswith(("global_", "flat_", "buffer_", "scratch_")) for l in before[w:bar]), before[max(0, bar - 12):bar + 1]
+    assert any(re.match(r"v_mov_b32_e32 v\d+, 1$", l) for l in before[bar:]), before[bar:]
+    assert not any(l.startswith(("s_bcnt1", "v_readfirstlane_b32")) and "exec" in l for l in before[bar:]), before[bar:]
+    after = ins[i + 1:i + 12]
+    assert "s_barrier" in after and after[0].startswith(("v_mov", "s_waitcnt")), after
+    # the finishing workgroup's loads of the partial sums
+    tail = ins[i:]
+    loads = [l for l in tail if l.startswith("global_load_dwordx2")]
+    assert len(loads) >= 2 and all(l.endswith(" sc1") for l in loads), loads
