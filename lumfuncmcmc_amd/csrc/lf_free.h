@@ -93,10 +93,14 @@ struct FreeArgs {
 // spares them a hand-over), and the LAST workgroup to finish a tile (a counter per tile, q[0]) does lf_finalize's for
 // them and leaves the tile's counters at zero for the next launch.  Two kernel boundaries fewer per evaluation:
 // measured 7 + 4.5 us of the 33 an evaluation of 128 rows took.
-template <int ST, bool CENSUS, bool FUSED = false>
-__global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeArrays na, const double* __restrict__ wrec_arg,
-                                                 const int* __restrict__ wmode_arg, FreeArgs fa) {
-    warm_kernarg<sizeof(KConst) + sizeof(SrcArrays) + sizeof(NodeArrays) + 2 * 8 + sizeof(FreeArgs)>();      // (lf_math.h: one round trip)
+// STEP (with FUSED): the launch is a half-step of the device-resident sampler - the tile's walkers are the stretch-move
+// PROPOSALS of the active half (made in the prologue by prepare_lane, as lf_prepare makes them: Philox keyed by (step, half,
+// walker), every workgroup of the tile the same values), and the tile's finishing workgroup accepts or rejects them and
+// writes the chain's row (accept_walker, as lf_finalize does).  An instantiation of its own behind a kernel of its own
+// (lf_free_step): the sampler's arguments are not in everybody's argument block.
+template <int ST, bool CENSUS, bool FUSED, bool STEP>
+__device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& sa, const NodeArrays& na, const double* __restrict__ wrec_arg,
+                                             const int* __restrict__ wmode_arg, const FreeArgs& fa, const StepArgs& sp, const AcceptArgs& ap) {
     const double* wrec = FUSED ? fa.wrec_w : wrec_arg;
     const int* wmode = FUSED ? fa.wmode_w : wmode_arg;
     // A partial sum: in the fused form it is read by a workgroup on another XCD while the launch is still running, so it
@@ -117,6 +121,9 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
     __shared__ int sstat[PTW];             // FUSED: the tile's status words, straight from the preparation
     __shared__ double sbase[PTW];          //        ... the closed-form part of piece A
     __shared__ double wlf[PTW * MAXF];     //        ... lF per (walker, field) (the careful path's)
+    __shared__ double sprop[PTW * 16];     // STEP:  ... the tile's proposals and stretch factors (the accept step's)
+    __shared__ double szz[PTW];
+    __shared__ double spre[PTW * 2];       //        ... and the accept step's two logarithms per walker, made ahead
     // ---- once per workgroup: the tables, and which XCD we are on.  (FUSED: waves 1..7 load them while wave 0 prepares the
     // first tile's walkers - see the top of the tile loop.)
     if (!FUSED) {
@@ -210,12 +217,14 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             // tables' one round trip to L2 overlap, one barrier ends both.  (Records written to memory, acknowledged, read
             // back by every wave, behind the tables' load: 8.0 of the launch's 19 us, tools/stamps_fused.py.)
             if (u < 64) {
-                prepare_lane<false, true>(kc, StepArgs{}, fa.theta, fa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
-                                          w0 + (u >> 3), u & 7, u >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, wlf
+                prepare_lane<false, true, STEP>(kc, sp, fa.theta, fa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
+                                          w0 + (u >> 3), u & 7, u >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, wlf,
 #ifdef LF_STAMPS
-                                          , s_tprep
+                                          s_tprep,
+#else
+                                          nullptr,
 #endif
-                                          );
+                                          sprop, szz);
 #ifdef LF_STAMPS
                 t_p0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -233,6 +242,15 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
 #ifdef LF_STAMPS
                 if (t7 == 0) s_ttab = __builtin_amdgcn_s_memtime();
 #endif
+            }
+            if (STEP && u >= PB - 64 && u < PB - 64 + nw) {
+                // (the last wave, idle once its share of the tables is on its way: the accept step's logarithms, from the same
+                // Philox draws as the proposal's stretch factor and the accept step's uniform - bit for bit what
+                // accept_walker would make in the epilogue)
+                const int wl = u - (PB - 64);
+                unsigned int rr[4];
+                sampler_draw(sp.step, sp.half, w0 + wl, 0, sp.seed, rr);
+                accept_terms(ap, w0 + wl, stretch_z(sp.a, u53(rr[0], rr[1])), spre[2 * wl], spre[2 * wl + 1]);
             }
             tables_loaded = true;
             __syncthreads();
@@ -689,7 +707,8 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
                 const int nB = fa.nchB > 0 ? fa.nslot : 0, nC = fa.nchC > 0 ? fa.nslot : 0;
                 if (v < nw)
                     finalize_wave<true>(fa.partA, fa.nchA, fa.nchA, fa.partB, nB, nB, nC > 0 ? fa.partC : nullptr, nC, (int)STAT_CELLS,
-                                        sstat - w0, sbase - w0, w0 + v, t & 63, AcceptArgs{}, fa.out, nullptr, nullptr);
+                                        sstat - w0, sbase - w0, w0 + v, t & 63, ap, fa.out, nullptr, nullptr, 0,
+                                        STEP ? sprop + v * 16 : nullptr, STEP ? szz + v : nullptr, STEP ? spre + 2 * v : nullptr);
                 if (t < QSTRIDE) q[t] = 0;        // the tile's counters, for the next launch
             }
         }
@@ -719,6 +738,19 @@ __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeAr
             !noitems ? t_red : (((s_ttab - stamp[0]) << 32) | ((t_p0 - stamp[0]) & 0xffffffffull));
     }
 #endif
+}
+
+template <int ST, bool CENSUS, bool FUSED = false>
+__global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeArrays na, const double* __restrict__ wrec_arg,
+                                                 const int* __restrict__ wmode_arg, FreeArgs fa) {
+    warm_kernarg<sizeof(KConst) + sizeof(SrcArrays) + sizeof(NodeArrays) + 2 * 8 + sizeof(FreeArgs)>();      // (lf_math.h: one round trip)
+    lf_free_body<ST, CENSUS, FUSED, false>(kc, sa, na, wrec_arg, wmode_arg, fa, StepArgs{}, AcceptArgs{});
+}
+
+template <int ST>
+__global__ __launch_bounds__(PB, 4) void lf_free_step(KConst kc, SrcArrays sa, NodeArrays na, FreeArgs fa, StepArgs sp, AcceptArgs ap) {
+    warm_kernarg<sizeof(KConst) + sizeof(SrcArrays) + sizeof(NodeArrays) + sizeof(FreeArgs) + sizeof(StepArgs) + sizeof(AcceptArgs)>();
+    lf_free_body<ST, false, true, true>(kc, sa, na, nullptr, nullptr, fa, sp, ap);
 }
 
 }  // namespace lf

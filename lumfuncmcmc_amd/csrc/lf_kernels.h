@@ -286,14 +286,15 @@ __device__ __forceinline__ int key_floor(double v) {
 // 8 x 16 LDS staging area `sth`.  BLOCK_SYNC: the 64 lanes are a workgroup of their own (lf_prepare) and meet at a
 // barrier; otherwise they are one wave of a larger workgroup (lf_free's fused prologue), in lockstep anyway.
 // nqueue > 0: the launch is lf_free's (the table keys and the cells' flag are wanted).
-template <bool BLOCK_SYNC, bool TOLDS = false>
+template <bool BLOCK_SYNC, bool TOLDS = false, bool STEP = BLOCK_SYNC>
 __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& sp, const double* __restrict__ theta, int B,
                                              double* __restrict__ wrec, int* __restrict__ wstat,
                                              int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
                                              int nqueue, int wq, int f, int grp, double (*sth)[16],
                                              double* __restrict__ l_fc = nullptr, double* __restrict__ l_sc = nullptr,
                                              int* __restrict__ l_stat = nullptr, double* __restrict__ l_base = nullptr,
-                                             double* __restrict__ l_lf = nullptr, unsigned long long* tst = nullptr) {
+                                             double* __restrict__ l_lf = nullptr, unsigned long long* tst = nullptr,
+                                             double* __restrict__ l_prop = nullptr, double* __restrict__ l_zz = nullptr) {
 #ifdef LF_STAMPS
 #define LF_TST(i) do { if (tst && wq % 8 == 0 && f == 0) tst[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -309,7 +310,7 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     const bool has_f = f < kc.nf;
     // theta row of this walker -> LDS: either the given row, or the stretch-move proposal
     //   y = x_j - (x_j - x_k) z,   z = ((a - 1) u + 1)^2 / a,   j uniform in the other half
-    if (BLOCK_SYNC && sp.enabled) {                  // (the fused prologue serves plain evaluations only)
+    if (STEP && sp.enabled) {                        // (STEP: this instantiation may be handed the sampler's half-step)
         unsigned int rr[4];
         sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
         const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
@@ -319,9 +320,13 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             const double xj = sp.pos[(size_t)j * sp.ndim + i], xk = sp.pos[(size_t)k * sp.ndim + i];
             const double y = stretch_point(xj, xk, z);
             sth[grp][i] = y;
-            if (live) sp.prop[(size_t)w * sp.ndim + i] = y;
+            // (TOLDS: the launch that proposes is the one that accepts - proposal and stretch factor stay in LDS: l_prop, l_zz)
+            if (TOLDS) l_prop[grp * 16 + i] = y;
+            else if (live) sp.prop[(size_t)w * sp.ndim + i] = y;
         }
-        if (live && f == 0) sp.zz[w] = z;
+        if (TOLDS) {
+            if (f == 0) l_zz[grp] = z;
+        } else if (live && f == 0) sp.zz[w] = z;
     } else {
         // (ndim <= 16: two elements per lane, both loads issued before either is waited for)
         const double* __restrict__ row = theta + (size_t)w * kc.ndim;
@@ -1506,16 +1511,31 @@ __global__ __launch_bounds__(BLOCK) void lf_main(KConst kc, SrcArrays sa, NodeAr
 // accept / reject walker k = half*halfW + w with the new lnprob `newlp`, and record it in the chain
 // (emcee keeps the state after the full step; a walker only changes in its own half-step).  One wave
 // per walker; lanes < ndim move the coordinates.
-__device__ __forceinline__ void accept_walker(const AcceptArgs& ap, int w, double newlp, int lane) {
-    const int k = ap.half * ap.halfW + w;
-    const double oldlp = ap.lnp[k];
+// (oldlp, zz, propv, posv: the walker's current lnprob, its stretch factor, and this lane's coordinate of the proposal and of the
+// current position - loaded by the caller, ahead of the sums the new lnprob comes from)
+// The accept step's two logarithms do not depend on the new lnprob: accept_terms makes them (the one-launch form: a wave that is
+// idle during the tile's preparation, so that the epilogue - the tail of the launch - is left with two adds and a compare).
+__device__ __forceinline__ void accept_terms(const AcceptArgs& ap, int w, double zz, double& lnz_term, double& logu) {
     unsigned int rr[4];
-    const long long t = ap.t;
     sampler_draw(ap.step, ap.half, w, 1, ap.seed, rr);
-    const double lnq = (ap.ndim - 1.0) * log(ap.zz[w]) + newlp - oldlp;
-    const bool acc = (log(u53(rr[0], rr[1])) < lnq) && (newlp > -__builtin_huge_val());
+    lnz_term = (ap.ndim - 1.0) * log(zz);
+    logu = log(u53(rr[0], rr[1]));
+}
+__device__ __forceinline__ void accept_walker(const AcceptArgs& ap, int w, double newlp, int lane, double oldlp, double zz, double propv,
+                                              double posv, const double* pre = nullptr) {
+    const int k = ap.half * ap.halfW + w;
+    const long long t = ap.t;
+    double lnz_term, logu;
+    if (pre) {
+        lnz_term = pre[0];
+        logu = pre[1];
+    } else {
+        accept_terms(ap, w, zz, lnz_term, logu);
+    }
+    const double lnq = lnz_term + newlp - oldlp;
+    const bool acc = (logu < lnq) && (newlp > -__builtin_huge_val());
     if (lane < ap.ndim) {
-        const double v = acc ? ap.prop[(size_t)w * ap.ndim + lane] : ap.pos[(size_t)k * ap.ndim + lane];
+        const double v = acc ? propv : posv;
         if (acc) ap.pos[(size_t)k * ap.ndim + lane] = v;
         ap.chain[((size_t)k * ap.cap + t) * ap.ndim + lane] = v;
     }
@@ -1548,7 +1568,8 @@ __global__ __launch_bounds__(64) void lf_propose(StepArgs sp) {
 __global__ __launch_bounds__(64) void lf_accept(AcceptArgs ap, const double* __restrict__ newlp) {
     const int w = blockIdx.x;
     if (w >= ap.halfW) return;
-    accept_walker(ap, w, newlp[w], threadIdx.x);
+    const int k = ap.half * ap.halfW + w, i = min((int)threadIdx.x, ap.ndim - 1);
+    accept_walker(ap, w, newlp[w], threadIdx.x, ap.lnp[k], ap.zz[w], ap.prop[(size_t)w * ap.ndim + i], ap.pos[(size_t)k * ap.ndim + i]);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1562,11 +1583,23 @@ template <bool COHERENT>
 __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int strideA, const double* partB, int nchB, int strideB,
                                               const double* partR, int nchR, int alt_flag, const int* wstat, const double* wbase,
                                               int w, int lane, const AcceptArgs& ap, double* out, double* outA, double* outB,
-                                              int a_flag = 0) {
+                                              int a_flag = 0, const double* l_prop = nullptr, const double* l_zz = nullptr,
+                                              const double* l_pre = nullptr) {
     auto ld = [](const double* p) -> double {
         if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return *p;
     };
+    // the sampler's half-step: what the accept step reads of the walker's state is on its way while the partial sums are added
+    // (l_prop / l_zz: proposal and stretch factor of the tile in LDS - the one-launch form; else in memory, lf_prepare's)
+    double s_old = 0.0, s_zz = 1.0, s_prop = 0.0, s_pos = 0.0;
+    if (ap.enabled) {
+        const int k = ap.half * ap.halfW + w;
+        const int i = min(lane, ap.ndim - 1);
+        s_old = ap.lnp[k];
+        s_pos = ap.pos[(size_t)k * ap.ndim + i];
+        s_zz = l_zz ? l_zz[0] : ap.zz[w];
+        s_prop = l_prop ? l_prop[i] : ap.prop[(size_t)w * ap.ndim + i];
+    }
     double a = 0.0, b = 0.0;
     // piece A of a walker with the alt_flag bit lies in partR: the compressed catalogue's SLOW walkers, summed over the
     // real catalogue by the rescue workgroups (alt_flag = STAT_SLOW); lf_free's walkers summed over cells (STAT_CELLS)
@@ -1602,8 +1635,9 @@ __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int
         if (outB) outB[w] = ok ? b : __builtin_nan("");
         a = r;                                   // lane 63 keeps the new lnprob for the accept step
     }
-    if (!COHERENT && ap.enabled)                     // (the fused epilogue serves plain evaluations only)
-        accept_walker(ap, w, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63)), lane);
+    if (ap.enabled)                                  // (the sampler's half-step: accept / reject and the chain's row)
+        accept_walker(ap, w, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63)), lane,
+                      s_old, s_zz, s_prop, s_pos, l_pre);
 }
 
 __global__ __launch_bounds__(64) void lf_finalize(const double* __restrict__ partA, int nchA, int strideA,

@@ -48,10 +48,10 @@ struct PersArgs {
     const int* wstat;
 };
 
-template <int VARIANT, bool FUSED>
-__global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
+// STEP (with FUSED): the launch is a half-step of the device-resident sampler (lf_free.h: lf_free_body)
+template <int VARIANT, bool FUSED, bool STEP>
+__device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& pa, const StepArgs& sp, const AcceptArgs& ap) {
     static_assert(VARIANT == LF_ZEVOL || VARIANT == LF_FIXCOMP, "the free variant has lf_free");
-    warm_kernarg<sizeof(KConst) + sizeof(PersArgs)>();      // (lf_math.h: the arguments in one round trip)
     auto pstore = [](double* p, double v) {                 // (see lf_free: partial sums are written THROUGH in the one-launch form)
         if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
@@ -64,6 +64,9 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
     __shared__ __attribute__((aligned(16))) double zcl[VARIANT == LF_ZEVOL ? PERS_MAXS * 2 : 2];      // the columns' {z, z^2}
     __shared__ int sstat[PTW];
     __shared__ double sbase[PTW];
+    __shared__ double sprop[PTW * 16];     // STEP: the tile's proposals and stretch factors (the accept step's)
+    __shared__ double szz[PTW];
+    __shared__ double spre[PTW * 2];       //       ... and the accept step's two logarithms per walker, made ahead (lf_free.h)
     __shared__ int smask[4];               // bit w: [0] walker on the cells, [1] needs the sources, [2] outside the prior (no grid)
     __shared__ int sdone;
     const int tid = threadIdx.x;
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
         // ---- prologue: the tile's records in LDS; the exp table (first tile)
         if (FUSED) {
             if (tid < 64) {
-                prepare_lane<false, true>(kc, StepArgs{}, pa.theta, pa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w0 + (tid >> 3), tid & 7,
-                                          tid >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, nullptr);
+                prepare_lane<false, true, STEP>(kc, sp, pa.theta, pa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w0 + (tid >> 3), tid & 7,
+                                                tid >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, nullptr, nullptr, sprop, szz);
             } else if (!tables_loaded && tid < 64 + 256) {
                 const int t = tid - 64;
                 double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * t);
@@ -129,6 +132,12 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
                 if (w < nw) wsc[t] = pa.wrec[(size_t)(w0 + w) * REC + j];
             }
             if (tid >= 128 && tid < 128 + nw) sstat[tid - 128] = pa.wstat[w0 + tid - 128];
+        }
+        if (FUSED && STEP && tid >= PB - 64 && tid < PB - 64 + nw) {
+            const int wl = tid - (PB - 64);
+            unsigned int rr[4];
+            sampler_draw(sp.step, sp.half, w0 + wl, 0, sp.seed, rr);
+            accept_terms(ap, w0 + wl, stretch_z(sp.a, u53(rr[0], rr[1])), spre[2 * wl], spre[2 * wl + 1]);
         }
         tables_loaded = true;
         __syncthreads();
@@ -360,8 +369,9 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
                 const int nC = VARIANT == LF_ZEVOL && pa.nchC > 0 ? pa.nslot : 0;
                 if (v < nw)
                     finalize_wave<true>(pa.partA, pa.nslot, pa.nslot, pa.partB, pa.nslot, pa.nslot, nC > 0 ? pa.partC : nullptr, nC, (int)STAT_CELLS,
-                                        sstat - w0, sbase - w0, w0 + v, lane, AcceptArgs{}, pa.out, nullptr, nullptr,
-                                        VARIANT == LF_FIXCOMP ? (int)STAT_SLOW : 0);      // (FIXCOMP: per-source partials exist for SLOW walkers only)
+                                        sstat - w0, sbase - w0, w0 + v, lane, ap, pa.out, nullptr, nullptr,
+                                        VARIANT == LF_FIXCOMP ? (int)STAT_SLOW : 0,       // (FIXCOMP: per-source partials exist for SLOW walkers only)
+                                        STEP ? sprop + v * 16 : nullptr, STEP ? szz + v : nullptr, STEP ? spre + 2 * v : nullptr);
                 if (tid < QSTRIDE) q[tid] = 0;    // the tile's counters, for the next launch
             }
         }
@@ -377,6 +387,18 @@ __global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
         kc.stamps[(size_t)gridDim.x * 8 + blockIdx.x] = ((t_cols - stamp[0]) << 32) | ((t_prep - stamp[0]) & 0xffffffffull);
     }
 #endif
+}
+
+template <int VARIANT, bool FUSED>
+__global__ __launch_bounds__(PB, 4) void lf_pers(KConst kc, PersArgs pa) {
+    warm_kernarg<sizeof(KConst) + sizeof(PersArgs)>();      // (lf_math.h: the arguments in one round trip)
+    lf_pers_body<VARIANT, FUSED, false>(kc, pa, StepArgs{}, AcceptArgs{});
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(PB, 4) void lf_pers_step(KConst kc, PersArgs pa, StepArgs sp, AcceptArgs ap) {
+    warm_kernarg<sizeof(KConst) + sizeof(PersArgs) + sizeof(StepArgs) + sizeof(AcceptArgs)>();
+    lf_pers_body<VARIANT, true, true>(kc, pa, sp, ap);
 }
 
 }  // namespace lf

@@ -79,6 +79,7 @@ struct lf_ctx {
     std::map<int, ChunkTable> chunks_free;   // the persistent FREE kernel's (lf_free.h): 512 ST sources per chunk, lanes of ST
     int64_t opt_persistent = 1;         // FREE: 1 = lf_free (persistent 512-thread workgroups) for catalogues that fill it
     int64_t opt_fuse = 1;               // lf_free: prepare and finalize inside the one launch (plain evaluations)
+    int64_t opt_fuse_step = 1;          // ... and the sampler's half-step too (0: three launches per half-step, A/B runs)
     bool queue_zero = false;            // d_queue is all zeros (what a fused launch needs and leaves behind)
     int64_t opt_free_st = 0;            // lf_free: sources per lane, 0 = chosen from N and B, else 2 / 4 / 8 (tuning runs)
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
@@ -597,13 +598,14 @@ int free_groups(lf_ctx* c, int slot, int ntiles, int nchA, int nchB, int nchC) {
 
 template <int ST>
 void launch_free(lf_ctx* c, int slot, int B, int ntiles, const lf::SrcArrays& sa, const lf::NodeArrays& na, lf::FreeArgs fa, hipStream_t s,
-                 bool fused) {
+                 bool fused, const lf::StepArgs* sp = nullptr, const lf::AcceptArgs* ap = nullptr) {
     // (fa.nslot is set by the caller from free_groups(), which is also what the grid is made of here)
     using namespace lf;
     const dim3 grid((unsigned)(8 * fa.tile_stride));
     const int info[8] = {ST, PTW, PTW, fused ? 3 : 2, (int)grid.x, fa.nchA, fa.nchB, B};
     std::memcpy(c->last_launch, info, sizeof(info));
-    if (fused) hipLaunchKernelGGL((lf_free<ST, false, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
+    if (fused && sp) hipLaunchKernelGGL((lf_free_step<ST>), grid, dim3(PB), 0, s, c->kc, sa, na, fa, *sp, *ap);      // the sampler's half-step
+    else if (fused) hipLaunchKernelGGL((lf_free<ST, false, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
     else if (c->kc.forms) hipLaunchKernelGGL((lf_free<ST, true>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
     else hipLaunchKernelGGL((lf_free<ST, false>), grid, dim3(PB), 0, s, c->kc, sa, na, c->d_wrec, c->d_wmode, fa);
 }
@@ -638,7 +640,9 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     }
     // One launch instead of three (lf_free.h: FUSED) for the plain evaluation; the sampler's propose / accept steps, the
     // two-piece diagnostics, the census and the profile of every launch keep lf_prepare and lf_finalize.
-    const bool fused = c->opt_fuse && !sp.enabled && !ap.enabled && !d_outA && !d_outB && d_out && !c->kc.forms && c->profiling < 2 &&
+    // ... and so is the sampler's half-step (proposal in the prologue, accept / reject by the tile's finishing workgroup)
+    const bool stepf = sp.enabled && ap.enabled && c->opt_fuse_step;
+    const bool fused = c->opt_fuse && (stepf || (!sp.enabled && !ap.enabled)) && !d_outA && !d_outB && d_out && !c->kc.forms && c->profiling < 2 &&
                        nchA + nchB > 0;
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
@@ -664,9 +668,10 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
-            if (st == 8) launch_free<8>(c, slot, B, ntiles, sa, na, fa, s, fused);
-            else if (st == 4) launch_free<4>(c, slot, B, ntiles, sa, na, fa, s, fused);
-            else launch_free<2>(c, slot, B, ntiles, sa, na, fa, s, fused);
+            const StepArgs* psp = fused && stepf ? &sp : nullptr;
+            if (st == 8) launch_free<8>(c, slot, B, ntiles, sa, na, fa, s, fused, psp, &ap);
+            else if (st == 4) launch_free<4>(c, slot, B, ntiles, sa, na, fa, s, fused, psp, &ap);
+            else launch_free<2>(c, slot, B, ntiles, sa, na, fa, s, fused, psp, &ap);
         }
     }
     if (!fused) {
@@ -709,7 +714,8 @@ int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, doubl
         c->cap_queue = cap;
         c->queue_zero = false;
     }
-    const bool fused = c->opt_fuse && !sp.enabled && !ap.enabled && !d_outA && !d_outB && d_out && c->profiling < 2;
+    const bool stepf = sp.enabled && ap.enabled && c->opt_fuse_step;       // the sampler's half-step: one launch too
+    const bool fused = c->opt_fuse && (stepf || (!sp.enabled && !ap.enabled)) && !d_outA && !d_outB && d_out && c->profiling < 2;
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->any_enqueued = true;
@@ -730,7 +736,8 @@ int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, doubl
         const dim3 grid((unsigned)(8 * g8));
         const int info[8] = {0, PTW, PTW, fused ? 5 : 4, (int)grid.x, nchC, nchB, B};
         std::memcpy(c->last_launch, info, sizeof(info));
-        if (fused) hipLaunchKernelGGL((lf_pers<VARIANT, true>), grid, dim3(PB), 0, s, c->kc, pa);
+        if (fused && stepf) hipLaunchKernelGGL((lf_pers_step<VARIANT>), grid, dim3(PB), 0, s, c->kc, pa, sp, ap);
+        else if (fused) hipLaunchKernelGGL((lf_pers<VARIANT, true>), grid, dim3(PB), 0, s, c->kc, pa);
         else hipLaunchKernelGGL((lf_pers<VARIANT, false>), grid, dim3(PB), 0, s, c->kc, pa);
     }
     if (!fused) {
@@ -1794,6 +1801,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     }
     if (std::strcmp(key, "fuse") == 0) {
         c->opt_fuse = value != 0;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "fuse_step") == 0) {
+        c->opt_fuse_step = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "profile_every") == 0) {

@@ -60,8 +60,8 @@ def test_persistent_free_kernel_fits_four_waves_per_simd_without_scratch(remarks
 
 @pytest.mark.parametrize("variant", [1, 2])
 def test_persistent_kernel_of_the_other_variants_fits_two_workgroups_per_cu(remarks, variant):
-    for fused in (0, 1):
-        for name, r in _find(remarks, "_ZN2lf7lf_persILi%dELb%dEEE" % (variant, fused)).items():
+    for prefix in ("_ZN2lf7lf_persILi%dELb0EEE" % variant, "_ZN2lf7lf_persILi%dELb1EEE" % variant, "_ZN2lf12lf_pers_stepILi%dEEE" % variant):
+        for name, r in _find(remarks, prefix).items():
             assert r["VGPRs"] <= 128 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
             assert r["LDS Size"] <= 80 * 1024, (name, r)
 
@@ -93,7 +93,8 @@ def _instr(lines):
     return [l for l in lines if l and not l.startswith((";", ".", "//")) and not l.endswith(":")]
 
 
-FUSED = [("_ZN2lf7lf_freeILi%dELb0ELb1EEE" % st) for st in (2, 4, 8)] + ["_ZN2lf7lf_persILi1ELb1EEE", "_ZN2lf7lf_persILi2ELb1EEE"]
+FUSED = [("_ZN2lf7lf_freeILi%dELb0ELb1EEE" % st) for st in (2, 4, 8)] + ["_ZN2lf7lf_persILi1ELb1EEE", "_ZN2lf7lf_persILi2ELb1EEE"] + \
+        [("_ZN2lf12lf_free_stepILi%dEEE" % st) for st in (2, 4, 8)] + ["_ZN2lf12lf_pers_stepILi1EEE", "_ZN2lf12lf_pers_stepILi2EEE"]
 
 
 @pytest.mark.parametrize("prefix", FUSED)
@@ -111,8 +112,9 @@ def test_one_launch_form_hands_its_partial_sums_over_through_memory(asm, prefix)
     ins = _instr(asm[names[0]])
     stores = [l for l in ins if l.startswith("global_store_dwordx2")]
     sc1_stores = [l for l in stores if l.endswith(" sc1")]
-    # (the kernel's only 8-byte stores to memory are the partial sums, written through, and lnprob itself)
-    assert len(sc1_stores) >= 2 and len(stores) - len(sc1_stores) <= 1, stores
+    # (the kernel's only 8-byte stores to memory are the partial sums, written through, lnprob itself and - the sampler's
+    # half-step - the accept step's few: position, chain row, lnprob, counter)
+    assert len(sc1_stores) >= 2 and len(stores) - len(sc1_stores) <= (8 if "_step" in prefix else 1), stores
     assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in ins), "a cache-wide write-back / invalidate crept in (154 us per evaluation)"
     # the count: wait - barrier - one-lane returning atomic - barrier
     at = [i for i, l in enumerate(ins) if l.startswith("global_atomic_add") and l.endswith(" sc0") and "offset" not in l]
@@ -130,4 +132,6 @@ def test_one_launch_form_hands_its_partial_sums_over_through_memory(asm, prefix)
     # the finishing workgroup's loads of the partial sums
     tail = ins[i:]
     loads = [l for l in tail if l.startswith("global_load_dwordx2")]
-    assert len(loads) >= 2 and all(l.endswith(" sc1") for l in loads), loads
+    plain = [l for l in loads if not l.endswith(" sc1")]
+    # (the half-step's accept reads the walker's current lnprob and position: data of earlier launches, plain loads)
+    assert len(loads) - len(plain) >= 2 and len(plain) <= (3 if "_step" in prefix else 0), loads

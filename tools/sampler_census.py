@@ -19,11 +19,12 @@ def main():
     ap.add_argument("--walkers", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--opts", default="", help="context options for the timed part, k=v,k=v")
+    ap.add_argument("--variant", default="free")
     ap.add_argument("--ball", type=float, default=0.0, help="start in a ball of this relative size around the box centre instead of box-uniform")
     a = ap.parse_args()
-    model = bench.build_model("free", a.nsrc, a.walkers, 0)
+    model = bench.build_model(a.variant, a.nsrc, a.walkers, 0)
     ctx = model.context()
-    th = synth.walkers("free", a.walkers, seed=1)
+    th = synth.walkers(a.variant, a.walkers, seed=1)
     if a.ball > 0:
         lims = np.array([th.min(axis=0), th.max(axis=0)])
         mid = lims.mean(axis=0)
