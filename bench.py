@@ -214,6 +214,7 @@ class Leg(object):
         from lumfuncmcmc_amd import synth
         from lumfuncmcmc_amd.dist import ShardedLnProb, SourceShardedLnProb, shard_sources, slice_bounds
         self.args, self.world, self.rank, self.shard, self.Wtot = args, world, rank, shard, Wtot
+        self.defer = False
         self.half = Wtot // 2
         self.nblk = nblk
         ki = model.kernel_inputs()
@@ -230,6 +231,7 @@ class Leg(object):
             self.create_s = time.perf_counter() - t0
             self.own_ctx = False
             self.ev = ShardedLnProb(self.ctx.lnprob_torch, self.ctx.ndim, dev, force_collective=args.force_collective)
+            self.defer = (world > 1 or args.force_collective) and args.pipeline_collective
             self.ki = ki
             bounds, _ = slice_bounds(self.half, world)
             self.row_lo, hi = bounds[rank]
@@ -260,9 +262,19 @@ class Leg(object):
         self.blocks = [torch.from_numpy(self.theta_all[i]).to(dev) for i in range(nblk)]
 
     def step(self, i):
+        if self.defer:
+            # the blocks of the plain loop are independent: the all-gather of one overlaps the kernel of the next
+            # (dist.ShardedLnProb: defer; complete at the fence, which flushes)
+            a = self.ev.evaluate_tensor(self.blocks[(2 * i) % self.nblk], defer=True)
+            b = self.ev.evaluate_tensor(self.blocks[(2 * i + 1) % self.nblk], defer=True)
+            return a, b
         a = self.ev.evaluate_tensor(self.blocks[(2 * i) % self.nblk])
         b = self.ev.evaluate_tensor(self.blocks[(2 * i + 1) % self.nblk])
         return a, b
+
+    def flush(self):
+        if self.defer:
+            self.ev.flush()
 
     def local_rows(self, used):
         """theta rows of the blocks `used` that THIS rank's kernels evaluate."""
@@ -298,6 +310,7 @@ def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1)
     t_settle = time.perf_counter()
     for i in range(SETTLE_STEPS):
         out = leg.step(i)
+    leg.flush()
     fence()
     per_step = (time.perf_counter() - t_settle) / SETTLE_STEPS
     more = int(min(SETTLE_SECONDS / max(per_step, 1e-6), 20000))
@@ -307,6 +320,7 @@ def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1)
         out = leg.step(i)
         if i % 64 == 63:
             fence_light(leg)
+    leg.flush()
     fence()
     leg.ctx.kernel_times()                      # clear
     # The event pairs that time the kernel are barrier packets: a bracketed launch no longer overlaps the tail of the one
@@ -320,6 +334,7 @@ def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1)
     for i in range(steps):
         out = leg.step(i)
         dbg.append(time.perf_counter() - t0)
+    leg.flush()
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -562,6 +577,11 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU path: initialise the process group and run the all-gather with one rank")
     ap.add_argument("--compress", action="store_true", help="time the compressed-catalogue option instead of the direct kernel (not the headline)")
+    ap.add_argument("--pipeline-collective", action="store_true",
+                    help="several GPUs, walker-sharded: do not wait for a block's all-gather before the next block's kernel (the plain "
+                         "loop's blocks are independent).  Off by default: measured with a one-rank RCCL group torch's asynchronous "
+                         "collectives cost more than they hide (30.4 against 28.4 us per 128-row call, 138 against 24.5 at 64 rows: "
+                         "profiles/r03_collective_rehearsal.txt)")
     ap.add_argument("--default-stream", action="store_true", help="launch on the legacy default stream instead of a side stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
@@ -648,6 +668,9 @@ def main():
         par = "source-sharded x%d (1/%d of every field's sources and of the grid chunks per GPU), %s all-reduce of lnprob" % (world, world, backend)
     else:
         par = "walker-sharded x%d, %s all-gather of lnprob" % (world, backend)
+        if leg.defer:
+            par += " (--pipeline-collective: a block's gather overlaps the next block's kernel)"
+
     res = None
     if rank == 0:
         res = {"metric": "walker-lnprob evals/sec (%s sources, %d walkers%s)" % (

@@ -34,6 +34,7 @@ class ShardedLnProb(object):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._buffers = {}
         self._flip = {}
+        self._pending = {}                  # (B, flip) -> work handle of a deferred gather into that buffer
         # check_theta: every call first verifies (one small all-reduce) that all ranks passed the SAME block - the
         # silent failure of this scheme is ranks whose samplers drifted apart (different seeds / starts)
         self.check_theta = bool(check_theta)
@@ -63,11 +64,22 @@ class ShardedLnProb(object):
             raise RuntimeError("ShardedLnProb: the ranks passed different theta blocks (rank %d): their samplers have "
                                "diverged - broadcast the start positions and the sampler seed from rank 0" % self.rank)
 
-    def evaluate_tensor(self, theta):
+    def flush(self):
+        """Wait (on the current stream; the host does not block for RCCL) for every deferred gather."""
+        for k in list(self._pending):
+            self._pending.pop(k).wait()
+
+    def evaluate_tensor(self, theta, defer=False):
         """theta: (B, ndim) float64 tensor on self.device -> (B,) tensor on self.device.  The local slice is
         written straight into the gather buffer (in-place all-gather: no staging copy, no allocation per call).
         Two gather buffers per B are used in turn, so the result of a call stays valid while the NEXT call with the
-        same B runs (a sampler holds half 0's lnprob while half 1 is evaluated); it is overwritten by the call after."""
+        same B runs (a sampler holds half 0's lnprob while half 1 is evaluated); it is overwritten by the call after.
+
+        defer = True: the gather is issued asynchronously (torch.distributed runs collectives on a stream of its own) and
+        NOT waited for here - the next evaluation's kernel overlaps it; the returned tensor is complete after flush() (or
+        after the second next call with the same B, which waits before it reuses the buffer).  For callers with independent
+        blocks to evaluate (bench.py's plain loop); a sampler needs block k before it can propose block k + 1 and keeps the
+        default."""
         torch, dist = self.torch, self.dist
         B = theta.shape[0]
         if not self._collective:
@@ -77,6 +89,9 @@ class ShardedLnProb(object):
         bounds, per = slice_bounds(B, self.world)
         lo, hi = bounds[self.rank]
         flip = self._flip[B] = 1 - self._flip.get(B, 1)
+        prev = self._pending.pop((B, flip), None)
+        if prev is not None:
+            prev.wait()                         # the gather that last used this buffer (two calls ago)
         full = self._buffers.get((B, flip))
         if full is None:
             full = torch.full((per * self.world,), float("-inf"), dtype=torch.float64, device=self.device)
@@ -92,6 +107,9 @@ class ShardedLnProb(object):
                 out.copy_(res)
         if not self._inplace and self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()        # gloo (rehearsal) does not order with our launches
+        if defer:
+            self._pending[(B, flip)] = dist.all_gather_into_tensor(full, mine, group=self.group, async_op=True)
+            return full[:B]
         try:
             dist.all_gather_into_tensor(full, mine, group=self.group)
         except RuntimeError:
@@ -110,7 +128,8 @@ class ShardedLnProb(object):
 
     def __call__(self, theta):
         t = self.torch.as_tensor(np.ascontiguousarray(theta, dtype=np.float64)).to(self.device)
-        return self.evaluate_tensor(t.reshape(-1, self.ndim)).cpu().numpy()
+        # (a copy: on a CPU device .numpy() would be a view of the gather buffer, which the call after next overwrites)
+        return np.array(self.evaluate_tensor(t.reshape(-1, self.ndim)).cpu().numpy(), copy=True)
 
 
 def shard_sources(inp, rank, world):

@@ -45,6 +45,18 @@ def _worker(rank, world, port, B, q):
     th = synth.walkers("fixcomp", B, seed=4)
     got = sh(th)
     ref = O.lnprob_batch(inp, th)
+    # deferred gathers (bench.py's plain loop: a block's gather overlaps the next block's evaluation): five independent
+    # blocks in a row, complete after flush() - and a buffer is only reused once its gather of two calls ago is done
+    blocks = [torch.from_numpy(synth.walkers("fixcomp", B, seed=20 + i)) for i in range(5)]
+    outs = [sh.evaluate_tensor(b, defer=True) for b in blocks[:2]]
+    kept = []
+    for b in blocks[2:]:
+        kept.append([o.clone() for o in outs[-2:]])            # (cloned while still valid: the NEXT call may reuse the older one)
+        outs.append(sh.evaluate_tensor(b, defer=True))
+    sh.flush()
+    for i in (3, 4):
+        assert np.array_equal(outs[i].numpy(), O.lnprob_batch(inp, blocks[i].numpy())), i
+    assert np.array_equal(sh.evaluate_tensor(blocks[0]).numpy(), O.lnprob_batch(inp, blocks[0].numpy()))
     # a short lock-step chain: every rank runs the same sampler on the sharded callable
     smp = EnsembleSampler(8, 3, sh, seed=11)
     p, lp, _ = smp.run_mcmc(synth.walkers("fixcomp", 8, seed=5), 3)
