@@ -216,9 +216,16 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             // the preparation's dependent chain (theta from memory, device-library exp10 / log10 / sqrt / log) and the
             // tables' one round trip to L2 overlap, one barrier ends both.  (Records written to memory, acknowledged, read
             // back by every wave, behind the tables' load: 8.0 of the launch's 19 us, tools/stamps_fused.py.)
-            if (u < 64) {
+            // Which wave prepares: wave 0 in the workgroups of the launch's first half, wave 1 in those of the second.  A CU
+            // holds workgroups i and i + 256 (the launch fills one slot of every CU before the second) and waves of equal index
+            // share a SIMD: two lone dependent chains of quarter-rate fp64 (divisions, sqrt, the library's exp10 / log10) on one
+            // SIMD took the younger workgroup 5k cycles longer than its elder (tools/stamps_fused.py) - and the launch ends
+            // with its slowest workgroup.
+            const int pw = (int)(blockIdx.x >> 8) & 1;
+            const int up = u - 64 * pw;           // the preparing wave's threads: 0 .. 63
+            if (up >= 0 && up < 64) {
                 prepare_lane<false, true, STEP>(kc, sp, fa.theta, fa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
-                                          w0 + (u >> 3), u & 7, u >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, wlf,
+                                          w0 + (up >> 3), up & 7, up >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, wlf,
 #ifdef LF_STAMPS
                                           s_tprep,
 #else
@@ -229,7 +236,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
                 t_p0 = __builtin_amdgcn_s_memtime();
 #endif
             } else if (!tables_loaded) {
-                const int t7 = u - 64;            // 0 .. 447
+                const int t7 = u < 64 * pw ? u : u - 64;      // the other seven waves' threads: 0 .. 447
                 // (all of a thread's loads in flight together: one round trip to the cold L2)
                 double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * min(t7, 255));
                 double et = EXP_TABLE[min(t7, 255)];

@@ -98,11 +98,15 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
         __syncthreads();                          // the previous tile's last reads of the LDS records are done
         // ---- prologue: the tile's records in LDS; the exp table (first tile)
         if (FUSED) {
-            if (tid < 64) {
-                prepare_lane<false, true, STEP>(kc, sp, pa.theta, pa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w0 + (tid >> 3), tid & 7,
-                                                tid >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, nullptr, nullptr, sprop, szz);
-            } else if (!tables_loaded && tid < 64 + 256) {
-                const int t = tid - 64;
+            // (the preparing wave: wave 0 in the launch's first 256 workgroups, wave 1 in the rest - the two workgroups of a CU
+            // keep their lone dependent chains on different SIMDs, lf_free.h)
+            const int pw = (int)(blockIdx.x >> 8) & 1;
+            const int up = tid - 64 * pw;
+            if (up >= 0 && up < 64) {
+                prepare_lane<false, true, STEP>(kc, sp, pa.theta, pa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w0 + (up >> 3), up & 7,
+                                                up >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, nullptr, nullptr, sprop, szz);
+            } else if (!tables_loaded && tid >= 128 && tid < 128 + 256) {
+                const int t = tid - 128;
                 double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * t);
                 double et = EXP_TABLE[t];
                 double2 zz = VARIANT == LF_ZEVOL ? *reinterpret_cast<const double2*>(pa.zcol + 2 * min(t, kc.S - 1)) : double2{0.0, 0.0};
