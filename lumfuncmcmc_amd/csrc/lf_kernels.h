@@ -256,16 +256,28 @@ __device__ __forceinline__ void sampler_draw(unsigned long long step, int half, 
 // short dependent chain.  set_parameters_from_list + lnprior: lumfuncmcmc.py:327-358,
 // lumfuncmcmc_z.py:339-362.
 // ----------------------------------------------------------------------------------------------
+// Butterfly over the 8 lanes of a walker on the DPP network: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then the mirrored
+// lane of the 8 (row_half_mirror; by then every lane of a quad holds the quad's total, so any lane of the other quad will
+// do).  The same sums in the same association as the __shfl_xor(1), (2), (4) butterfly it replaces - whose ds_bpermutes
+// (two per step for a double, an LDS round trip each) were 1.4k cycles of the lone wave that prepares a tile.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
+}
 __device__ __forceinline__ double group8_sum(double v) {
-    v += __shfl_xor(v, 1, 8);
-    v += __shfl_xor(v, 2, 8);
-    v += __shfl_xor(v, 4, 8);
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
     return v;
 }
 __device__ __forceinline__ int group8_or(int v) {
-    v |= __shfl_xor(v, 1, 8);
-    v |= __shfl_xor(v, 2, 8);
-    v |= __shfl_xor(v, 4, 8);
+    v |= dpp_mov<0xB1>(v);
+    v |= dpp_mov<0x4E>(v);
+    v |= dpp_mov<0x141>(v);
     return v;
 }
 

@@ -21,8 +21,12 @@ def main():
     ap.add_argument("--variant", default="free")
     ap.add_argument("--opts", default="", help="context options, k=v,k=v")
     ap.add_argument("--levels", default="0,1,2,0", help="profiling levels to run")
+    ap.add_argument("--lib", default="", help="A/B: another build of the library (path to a .so)")
     ap.add_argument("--default-stream", action="store_true", help="launch on the null stream instead of a stream of our own")
     a = ap.parse_args()
+    if a.lib:
+        from lumfuncmcmc_amd import capi
+        capi.LIB_PATH = os.path.abspath(a.lib)
     model = bench.build_model(a.variant, a.nsrc, 2 * a.rows, 0)
     ctx = model.context()
     th = [torch.from_numpy(synth.walkers(a.variant, a.rows, seed=s)).cuda() for s in (1, 2, 3, 4)]
