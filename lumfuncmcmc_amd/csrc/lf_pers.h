@@ -189,19 +189,16 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
                         d[2 * k + 1] = i < pa.ncell ? a.y : 0.0;
                     }
                 };
-                // (two chunks ahead: a chunk's arithmetic is a few hundred cycles, its loads a round trip to a cold L2)
-                double nx[8], nx2[8];
+                // (one chunk ahead; two were measured and gained nothing - the phase is bound by issue, not by the loads - and
+                // their 16 registers pushed the kernel into scratch)
+                double nx[8];
                 if (cfirst < pa.nchC) load_cell(nx, cfirst);
-                if (cfirst + VF < pa.nchC) load_cell(nx2, cfirst + VF);
 #pragma unroll 1
                 for (int cc = cfirst; cc < pa.nchC; cc += VF) {
                     double cd[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        cd[k] = nx[k];
-                        nx[k] = nx2[k];
-                    }
-                    if (cc + 2 * VF < pa.nchC) load_cell(nx2, cc + 2 * VF);
+                    for (int k = 0; k < 8; ++k) cd[k] = nx[k];
+                    if (cc + VF < pa.nchC) load_cell(nx, cc + VF);
                     asm volatile("; LF_BEGIN pzcell items=1");
                     const double zc2 = cd[0] * cd[0];
                     const double Lc = quad_nofma(aL, bL, cL, cd[0], zc2);

@@ -38,7 +38,7 @@ json.dump(summary, open(os.path.join(here, "%s_pmc.json" % tag), "w"), indent=1,
 # compressed-catalogue one, whose launches read a few hundred KB): the one with the largest fetch
 def product(k):                # lf_main, or lf_free<ST, false, .>: not the census instantiation lf_free<ST, true, false>
     import re
-    return "lf_main" in k or re.search(r"lf_free<\d+, false", k) is not None
+    return "lf_main" in k or re.search(r"lf_free<\d+, false", k) is not None or re.search(r"lf_pers<\d+, true", k) is not None
 
 
 dom = sorted([k for k in summary if product(k) and "FETCH_SIZE" in summary[k]], key=lambda k: -summary[k]["_launches_sampled"])
