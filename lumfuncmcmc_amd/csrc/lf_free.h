@@ -157,8 +157,8 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
     int nitems_done = 0;
     unsigned long long t_first = 0, t_sw = 0, t_loop = 0, t_red = 0;
     unsigned long long t_prep = 0, t_cells = 0, t_grid = 0;      // (the last tile's: after the records are in LDS, the cells, the grid)
-    unsigned long long t_p0 = 0;                                 // wave 0 back from the preparation
     __shared__ unsigned long long s_ttab;                        // wave 1 done with its share of the tables
+    __shared__ unsigned long long s_tp0;                         // the preparing wave back from prepare_lane
     __shared__ unsigned long long s_tprep[8];                    // inside the preparation: entry, theta in LDS, Q made, keys made, before the combine
 #endif
 
@@ -233,7 +233,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
 #endif
                                           sprop, szz);
 #ifdef LF_STAMPS
-                t_p0 = __builtin_amdgcn_s_memtime();
+                if (up == 0) s_tp0 = __builtin_amdgcn_s_memtime();
 #endif
             } else if (!tables_loaded) {
                 const int t7 = u < 64 * pw ? u : u - 64;      // the other seven waves' threads: 0 .. 447
@@ -742,7 +742,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
         }
         stamp[6] = __builtin_amdgcn_s_memrealtime();
         kc.stamps[(size_t)gridDim.x * 8 + blockIdx.x] =             // barrier C, reduction, stores  (second table behind the first)
-            !noitems ? t_red : (((s_ttab - stamp[0]) << 32) | ((t_p0 - stamp[0]) & 0xffffffffull));
+            !noitems ? t_red : (((s_ttab - stamp[0]) << 32) | ((s_tp0 - stamp[0]) & 0xffffffffull));
     }
 #endif
 }
