@@ -159,10 +159,12 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * g(num) = ln fc and h(y) = 1 / (1 - e^(-10^y)) (piecewise degree-7 polynomials, relative error <= 8e-15 over their
  * whole domain, lf_tables.h), for (walker, chunk) pairs whose fluxes lie inside the tables and whose lanes of
  * flux-neighbours are narrower than the tables' margins; 0 = always the general form (A/B runs).
- * "persistent": 1 (default) runs the free variant's direct path in lf_free - persistent 512-thread workgroups that
- * hold the g / h tables in LDS, serve one tile of 8 walkers and pull catalogue and grid chunks from per-XCD queues -
- * whenever the catalogue and the grid give every workgroup about four items (e.g. N >= 1.8e5 at 128 rows, N = 1e6
- * from 64 rows); 0 = always lf_main; 2 = always lf_free (tests).  "free_st": sources per lane of lf_free, 0 (auto: 8
+ * "persistent": 1 (default) runs the direct path in the persistent kernels - 512-thread workgroups, two per CU, that
+ * hold the tables in LDS and serve one tile of 8 walkers per group of workgroups: lf_free (free completeness: whenever
+ * the context has cells - every catalogue up to 65 536 sources and every larger one with at least four sources per
+ * cell - or else when catalogue and grid give every workgroup about four chunks) and lf_pers (fixed completeness
+ * always; z-evolving when the context has cells in redshift, one set of L nodes per redshift column and at most 256
+ * columns); 0 = always lf_main; 2 = always the persistent kernel (tests).  "free_st": sources per lane of lf_free, 0 (auto: 8
  * for N >= 3e5, else 4), 2, 4 or 8 (tuning runs).  "cells": 1 (default) lets lf_free sum a walker whose every field lies inside the tables over the
  * catalogue's CELLS instead of its sources: runs of flux-neighbouring sources no wider than 2 rho, kept as their
  * midpoint and power sums S_0 .. S_8; on a table piece the term is a polynomial in the flux offset, so a cell's sum is
@@ -171,9 +173,12 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * redshift: what is left of its term per source is a weight times exp of a parabola in z, summed as a series in the
  * weighted power sums of a run of redshift neighbours (orders above 6 below 1e-17; the cells' width is chosen from the
  * prior box of L1..L3 so that every walker inside it qualifies).  0 = every walker over the sources (A/B runs).
- * "fuse": 1 (default) lets lf_free do lf_prepare's and lf_finalize's work itself for plain evaluations - one launch
- * instead of three, same bits; 0 = three launches (A/B runs; the sampler's steps, lf_lnprob_pieces, the census and
- * profiling level 2 always take three).  "profile_every": see lf_set_profiling.
+ * "fuse": 1 (default) lets lf_free / lf_pers do lf_prepare's and lf_finalize's work themselves for plain evaluations -
+ * one launch instead of three, same bits; 0 = three launches (A/B runs; lf_lnprob_pieces, the census, profiling level 2
+ * and the walker-sharded sampler's halves always take three).  "fuse_step": 1 (default) makes a half-step of the
+ * device-resident sampler ONE launch of the same kernels (proposal in the prologue, accept / reject and the chain's row
+ * by the tile's finishing workgroup); 0 = lf_propose+prepare, kernel, lf_finalize+accept (same chain, bit for bit).
+ * "profile_every": see lf_set_profiling.
  * "grid_shortcut": 1 (default) lets lf_free take piece B of a FREE context whose integration grid is separable (every
  * redshift column has the same luminosity nodes: min_comp_frac = 0) over FLUX BINS instead of the S^2 lattice points: the
  * completeness depends on a lattice point only through its log flux L_j - D_k, so per bin the lattice points of a row are
@@ -206,7 +211,8 @@ int lf_form_counts(lf_ctx *ctx, int64_t counts[9]);
 /* Shape of the most recent lf_main launch of this context (measurement only): info[0..7] = sources per lane, walkers
  * per source workgroup and per grid workgroup of the instantiation (template parameters ST, TW, TWB); which kernel ran
  * (0 lf_main, 1 its compressed-catalogue instantiation, 2 lf_free: the persistent kernel of the free variant, 3
- * lf_free in its one-launch form, see "fuse");
+ * lf_free in its one-launch form, see "fuse"; 4 lf_pers: the persistent kernel of the other two variants, 5 lf_pers in
+ * its one-launch form);
  * workgroups in the launch, catalogue chunks, grid chunks, theta rows. */
 int lf_last_launch(const lf_ctx *ctx, int32_t info[8]);
 
@@ -216,7 +222,8 @@ int lf_last_launch(const lf_ctx *ctx, int32_t info[8]);
  * and the chain kept in HBM.  Replaces
  *     sampler = emcee.EnsembleSampler(nwalkers, ndim, lnprob); sampler.run_mcmc(pos, nsteps)
  *     sampler.chain, sampler.lnprobability, sampler.acceptance_fraction      lumfuncmcmc.py:489-513
- * One step = 2 x (propose+prepare, main, finalize+accept) = 6 launches, no host round trip.
+ * One step = 2 half-steps of ONE launch each where the persistent kernels serve the context (option "fuse_step"),
+ * else 2 x (propose+prepare, main, finalize+accept) = 6 launches; no host round trip either way.
  * Random numbers are Philox4x32-10 keyed by `seed`: the chain is a pure function of (seed, start).
  */
 typedef struct lf_sampler lf_sampler;
