@@ -32,6 +32,16 @@ constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalo
 // partial sums - and with them the bits of its lnprob - do not depend on how many rows share its call, on its place in
 // the batch, or on how a batch is sharded over GPUs.
 constexpr int VF = 32;
+// The deal table: [0 .. VF] where rank vr's cell chunks start in the list, [VF + 1 .. 2 VF + 1] the same for its bins, then the
+// list (cell chunks rank by rank, then bins rank by rank).  Who gets what is decided by COST: a flux bin costs a wave about
+// 2.7 cell chunks, and the workgroups of ranks >= VF / 2 are the younger ones of their CUs, ~1.3 cell chunks behind their
+// elders when the sums begin (tools/stamps_fused.py) - the host deals bins, then cells, each to the rank that would be done
+// first.  With the arithmetic deal (bin c to rank c mod VF, cell chunk cc to rank (cc + VF / 2) mod VF) the busiest rank of the
+// benchmark's context had a bin and two cell chunks (10.4k cycles), the average being 6.6k, and the 17th bin sat on a younger
+// rank with two cell chunks of its own.  A context's table depends on its numbers of bins and cell chunks only: a row's
+// partial sums (one per virtual rank) are the same whatever the batch.
+constexpr int DEAL_BINS = VF + 1, DEAL_LIST = 2 * (VF + 1), DEAL_MAX = 512;
+constexpr int TOUCH_PER = 4;          // touches per lane and rank (256 lines = 32 KB: three cell chunks and a bin of 30 rows)
 
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
 // (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
@@ -66,9 +76,10 @@ struct FreeArgs {
     const double* cells;      // [nchC * 64][CELL_REC] {x_c, S_0 .. S_8}: every field's cells padded to whole chunks of 64 (pads: all sums 0)
     const double* nodes8;     // [nchB * 64][8] {G, PG, W, a3, a4, the chunk's smallest a4, -, -}: the grid's nodes, one 64-byte
                               // record per node, padded to whole chunks (pads: W = 0)
-    const int* cc_start;      // [nchC] first cell of a cell chunk
+    const int* deal;          // the static deal of cell chunks and flux bins to the VF virtual workgroups (DEAL_* below; made by the
+                              // host from the chunks' costs: lfmcmc.hip, ensure_deal) or NULL = the arithmetic deal
     const int* cc_len;        // [nchC] its cells (<= 64: one per lane of a wave; the waves take one walker each)
-    const int* cc_field;      // [nchC]
+    const int* touch;         // [VF][TOUCH_PER][64] the 128-byte lines rank vr's workgroup touches ahead (buffer << 28 | line; -1 none), or NULL
     int nchC;                 // cell chunks (64 cells; 0: no cells)
     double* partC;            // [B][nslot]: the cells' sums, likewise
     const int* wstat;         // [B]
@@ -100,7 +111,8 @@ struct FreeArgs {
 // (lf_free_step): the sampler's arguments are not in everybody's argument block.
 template <int ST, bool CENSUS, bool FUSED, bool STEP>
 __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& sa, const NodeArrays& na, const double* __restrict__ wrec_arg,
-                                             const int* __restrict__ wmode_arg, const FreeArgs& fa, const StepArgs& sp, const AcceptArgs& ap) {
+                                             const int* __restrict__ wmode_arg, const FreeArgs& fa, const StepArgs& sp, const AcceptArgs& ap,
+                                             unsigned long long t_pre = 0) {
     const double* wrec = FUSED ? fa.wrec_w : wrec_arg;
     const int* wmode = FUSED ? fa.wmode_w : wmode_arg;
     // A partial sum: in the fused form it is read by a workgroup on another XCD while the launch is still running, so it
@@ -116,6 +128,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
     __shared__ __attribute__((aligned(16))) double wfc[PTW * MAXF * 8];   // per (walker, field): aC, V, cA, cYs, {mode, klo, khi, kne, kaC}, cYH
     __shared__ __attribute__((aligned(16))) double wsc[PTW * 8];          // per walker: L*, c0, c1, Q, alpha_C
     __shared__ int sitem[2];
+    __shared__ int sdeal[DEAL_MAX];        // the deal table (fa.deal), with the tables
     __shared__ int scell;                  // bit w: walker w of the tile is summed over the cells
     const int tid = threadIdx.x;
     __shared__ int sstat[PTW];             // FUSED: the tile's status words, straight from the preparation
@@ -132,6 +145,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             tab.expt[i] = EXP_TABLE[i];
         }
         load_term_tables<PB>(&tt);
+        if (fa.deal && tid < DEAL_LIST + fa.nchC + fa.nbq) sdeal[tid] = fa.deal[tid];      // (<= DEAL_MAX = PB entries)
     }
     bool tables_loaded = !FUSED;
     // The thread number, made anew wherever it is needed (wave index from a scalar register, lane from mbcnt on an opaque
@@ -149,10 +163,12 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int myq = (int)(xcc & 7u);
 #ifdef LF_STAMPS
+    __shared__ unsigned long long s_targs;                       // arguments in (wave 0)
     unsigned long long* stamp = kc.stamps ? kc.stamps + (size_t)blockIdx.x * 8 : nullptr;
     if (stamp && tid == 0) {
-        stamp[0] = __builtin_amdgcn_s_memtime();
+        stamp[0] = t_pre ? t_pre : __builtin_amdgcn_s_memtime();       // (the wave's first instruction, before its arguments)
         stamp[5] = __builtin_amdgcn_s_memrealtime();
+        s_targs = __builtin_amdgcn_s_memtime();
     }
     int nitems_done = 0;
     unsigned long long t_first = 0, t_sw = 0, t_loop = 0, t_red = 0;
@@ -207,8 +223,9 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             if (ticket < hi - lo) return lo + ticket;
             return grab();                        // our queue is empty: steal (the grid queue and ours just hand out misses)
         };
-        __syncthreads();                          // the previous tile's last reads of wfc / wsc / sitem are done
+        if (tile != ((int)blockIdx.x >> 3) % fa.ntiles) __syncthreads();      // the previous tile's last reads of wfc / wsc / sitem are done
         const int u = fresh_tid();
+        int touched[2 * TOUCH_PER] = {};                   // (see the prologue's touches)
         if (FUSED) {
             // Wave 0 prepares the tile's 8 walkers (lf_prepare's body) and puts their records straight into LDS (wfc, wsc,
             // wlf, sstat, sbase: the one-launch form writes no records to memory - the launch that makes them is the only
@@ -224,7 +241,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             const int pw = (int)(blockIdx.x >> 8) & 1;
             const int up = u - 64 * pw;           // the preparing wave's threads: 0 .. 63
             if (up >= 0 && up < 64) {
-                prepare_lane<false, true, STEP>(kc, sp, fa.theta, fa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
+                prepare_lane<false, true, STEP, LF_FREE>(kc, sp, fa.theta, fa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
                                           w0 + (up >> 3), up & 7, up >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, wlf,
 #ifdef LF_STAMPS
                                           s_tprep,
@@ -240,15 +257,53 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
                 // (all of a thread's loads in flight together: one round trip to the cold L2)
                 double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * min(t7, 255));
                 double et = EXP_TABLE[min(t7, 255)];
-                asm volatile("" : "+v"(lt.x), "+v"(lt.y), "+v"(et));
+                const int ndeal = fa.deal ? DEAL_LIST + fa.nchC + fa.nbq : 0;     // (<= DEAL_MAX: two entries per thread of the 448)
+                int d0 = ndeal ? fa.deal[min(t7, ndeal - 1)] : 0, d1 = ndeal ? fa.deal[min(t7 + 256, ndeal - 1)] : 0;
+                asm volatile("" : "+v"(lt.x), "+v"(lt.y), "+v"(et), "+v"(d0), "+v"(d1));
                 load_term_tables<PB - 64>(&tt, t7);
                 if (t7 < 256) {
                     tab.logt[t7] = lt;
                     tab.expt[t7] = et;
+                    if (t7 < ndeal) sdeal[t7] = d0;
+                    if (t7 + 256 < ndeal) sdeal[t7 + 256] = d1;
                 }
 #ifdef LF_STAMPS
                 if (t7 == 0) s_ttab = __builtin_amdgcn_s_memtime();
 #endif
+                // One of these waves, idle until the preparing wave is back: TOUCH what this workgroup's ranks will read after
+                // the barrier - their cell chunks, their bins' records and the bins' row weights - one dword per 128-byte
+                // line, so that the lines are in this XCD's L2 by then.  Nothing of a launch's inputs is in a cache when it
+                // starts, a wave holds one chunk ahead at most, and a trip to memory is ~2k cycles: a rank with three cell
+                // chunks spent 10k cycles on them (3.4k per chunk for 0.7k of arithmetic), a bin 6.7k.  The rank's entries
+                // of the deal table come by scalar loads (the table itself is only on its way to LDS).  The values go
+                // nowhere: the sink below, behind the barrier, keeps the loads where they are.
+                if (t7 >= 320 && t7 < 384 && fa.touch) {
+                    // (the lines come from a table the host made with the deal: one entry per lane and slot, two round trips in
+                    // all - the entries, then the touches, all of them in flight together; the first two of the workgroup's ranks)
+                    const int ln = t7 - 320;
+                    int e[2][TOUCH_PER];
+                    // (the three buffers' addresses as opaque scalars: left to itself the compiler picks the pointer by a VECTOR load
+                    // from the argument segment, indexed by the entry's buffer number - and every touch waits for its own)
+                    unsigned long long pb0 = reinterpret_cast<unsigned long long>(fa.cells), pb1 = reinterpret_cast<unsigned long long>(fa.gq_rec),
+                                       pb2 = reinterpret_cast<unsigned long long>(fa.gq_omega), pbn = reinterpret_cast<unsigned long long>(fa.touch);
+                    asm volatile("" : "+s"(pb0), "+s"(pb1), "+s"(pb2), "+s"(pbn));
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int i = 0; i < TOUCH_PER; ++i) e[k][i] = fa.touch[(min(frank + k * fgroup, VF - 1) * TOUCH_PER + i) * 64 + ln];
+                    static_assert(TOUCH_PER == 4, "the pin below");
+                    asm volatile("" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]), "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[1][2]), "+v"(e[1][3]));
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int i = 0; i < TOUCH_PER; ++i) {
+                            const int b = e[k][i] >> 28;
+                            const bool have = e[k][i] >= 0 && frank + k * fgroup < VF;
+                            const unsigned long long at = have ? (b == 0 ? pb0 : b == 1 ? pb1 : pb2) + (unsigned long long)(e[k][i] & 0x0fffffff) * 128ull : pbn;
+                            typedef const int __attribute__((address_space(1))) global_int;      // (a global load, not a flat one)
+                            touched[TOUCH_PER * k + i] = *reinterpret_cast<global_int*>(at);
+                        }
+                }
             }
             if (STEP && u >= PB - 64 && u < PB - 64 + nw) {
                 // (the last wave, idle once its share of the tables is on its way: the accept step's logarithms, from the same
@@ -261,6 +316,8 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             }
             tables_loaded = true;
             __syncthreads();
+            asm volatile("" :: "v"(touched[0]), "v"(touched[1]), "v"(touched[2]), "v"(touched[3]), "v"(touched[4]), "v"(touched[5]), "v"(touched[6]),
+                         "v"(touched[7]));
         }
         if (u < 64) {
             // which walkers of the tile lf_prepare put on the cells (one load per lane); when all of them are, the sources
@@ -338,8 +395,13 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             // a bin of the grid costs three cell chunks: so the bins go to the elders (rank c mod VF, from 0 up) and the
             // cell chunks are dealt from the middle (chunk cc to rank (cc + VF / 2) mod VF): the younger half gets cells
             // first and no bins.
+            // (the host's deal - DEAL_* above - where there is one: this rank's chunks are entries cb .. cb + cn - 1 of the list)
+            const bool dealt = fa.deal != nullptr;
             const int cfirst = (vr - VF / 2 + VF) % VF;
-            if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && cfirst < fa.nchC) {       // (wave-uniform)
+            const int cb = dealt ? DEAL_LIST + uni(sdeal[vr]) : cfirst;
+            const int cn = dealt ? uni(sdeal[vr + 1]) - uni(sdeal[vr]) : (cfirst < fa.nchC ? (fa.nchC - cfirst + VF - 1) / VF : 0);
+            auto chunk_at = [&](int i) { return dealt ? uni(sdeal[cb + i]) : cb + i * VF; };
+            if (fa.nchC > 0 && v < nw && ((cellmask >> v) & 1) && cn > 0) {       // (wave-uniform)
                 // (Nothing but these loads goes through the vector memory counter inside the loop - chunk cc starts at cell
                 // 64 cc, its field comes from KConst by scalar compares, pads need no masking - so the next chunk's cells
                 // really are in flight while the current chunk is summed.  With the chunk table read from memory and the
@@ -362,13 +424,14 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
                     return f;
                 };
                 double nx[CELL_REC];
-                load_cells(nx, cfirst);
+                load_cells(nx, chunk_at(0));
 #pragma unroll 1
-                for (int cc = cfirst; cc < fa.nchC; cc += VF) {
+                for (int ci = 0; ci < cn; ++ci) {
+                    const int cc = chunk_at(ci);
                     double cd[CELL_REC];
 #pragma unroll
                     for (int k = 0; k < CELL_REC; ++k) cd[k] = nx[k];
-                    if (cc + VF < fa.nchC) load_cells(nx, cc + VF);
+                    if (ci + 1 < cn) load_cells(nx, chunk_at(ci + 1));
                     const WalkerK p = fetch(v, field_of(cc));
                     asm volatile("; LF_BEGIN cell items=1");
                     acc += cell_sum(cd, p, &tt);
@@ -399,8 +462,11 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             for (int vr = frank; vr < VF; vr += fgroup) {
             double bsum = 0.0;
             // (bin c goes to the virtual workgroup of rank c mod VF: see the cells' deal above)
-            const int first = vr;
-            if (v < nw && first < nq) {
+            const bool dealt = fa.deal != nullptr;
+            const int qb = dealt ? DEAL_LIST + fa.nchC + uni(sdeal[DEAL_BINS + vr]) : vr;
+            const int qn = dealt ? uni(sdeal[DEAL_BINS + vr + 1]) - uni(sdeal[DEAL_BINS + vr]) : (vr < nq ? (nq - vr + VF - 1) / VF : 0);
+            auto bin_at = [&](int i) { return dealt ? uni(sdeal[qb + i]) : qb + i * VF; };
+            if (v < nw && qn > 0) {
                 const double* __restrict__ sc = wsc + v * 8;
                 const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(wfc + (v * MAXF) * 8 + 4));
                 const double* __restrict__ r = wfc + v * MAXF * 8 - 8;   // RF(f, slot) = 8 + 8 f + slot
@@ -419,12 +485,13 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
                     return QRec{a.x, a.y, b.x, b.y};
                 };
                 double* __restrict__ Tl = red + v * 64;      // this wave's Schechter values, one row per lane
-                QRec nx = load_rec(first);
+                QRec nx = load_rec(bin_at(0));
 #pragma unroll 1
-                for (int c = first; c < nq; c += VF) {
+                for (int qi = 0; qi < qn; ++qi) {
+                    const int c = bin_at(qi);
                     const QRec nd = nx;
                     const int nr = uni(fa.gq_rows[4 * c + 1]), off = uni(fa.gq_rows[4 * c + 2]);
-                    if (c + VF < nq) nx = load_rec(c + VF);
+                    if (qi + 1 < qn) nx = load_rec(bin_at(qi + 1));
                     if (mine(c)) {
                         const int lane = fresh_tid() & 63;
                         const double* __restrict__ om = fa.gq_omega + off + lane;
@@ -733,7 +800,8 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             stamp[7] = t_grid - stamp[0];
             // (the preparation's inner time line goes where the items count would be: 4 x 16 bits, units of 16 cycles)
             unsigned long long pk = 0;
-            for (int i = 0; i < 4; ++i) pk |= (((s_tprep[i + 1] - stamp[0]) >> 4) & 0xffffull) << (16 * i);
+            pk = ((s_targs - stamp[0]) >> 4) & 0xfffull;
+            for (int i = 0; i < 4; ++i) pk |= (((s_tprep[i] - stamp[0]) >> 4) & 0xfffull) << (12 * (i + 1));
             stamp[2] = pk;
         } else {
             stamp[3] = t_first ? t_first - stamp[0] : 0;      // prologue: tables, tile constants, first claim
@@ -750,8 +818,13 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
 template <int ST, bool CENSUS, bool FUSED = false>
 __global__ __launch_bounds__(PB, 4) void lf_free(KConst kc, SrcArrays sa, NodeArrays na, const double* __restrict__ wrec_arg,
                                                  const int* __restrict__ wmode_arg, FreeArgs fa) {
+#ifdef LF_STAMPS
+    const unsigned long long t_pre = __builtin_amdgcn_s_memtime();
+#else
+    const unsigned long long t_pre = 0;
+#endif
     warm_kernarg<sizeof(KConst) + sizeof(SrcArrays) + sizeof(NodeArrays) + 2 * 8 + sizeof(FreeArgs)>();      // (lf_math.h: one round trip)
-    lf_free_body<ST, CENSUS, FUSED, false>(kc, sa, na, wrec_arg, wmode_arg, fa, StepArgs{}, AcceptArgs{});
+    lf_free_body<ST, CENSUS, FUSED, false>(kc, sa, na, wrec_arg, wmode_arg, fa, StepArgs{}, AcceptArgs{}, t_pre);
 }
 
 template <int ST>

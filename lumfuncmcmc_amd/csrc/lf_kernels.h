@@ -298,7 +298,7 @@ __device__ __forceinline__ int key_floor(double v) {
 // 8 x 16 LDS staging area `sth`.  BLOCK_SYNC: the 64 lanes are a workgroup of their own (lf_prepare) and meet at a
 // barrier; otherwise they are one wave of a larger workgroup (lf_free's fused prologue), in lockstep anyway.
 // nqueue > 0: the launch is lf_free's (the table keys and the cells' flag are wanted).
-template <bool BLOCK_SYNC, bool TOLDS = false, bool STEP = BLOCK_SYNC>
+template <bool BLOCK_SYNC, bool TOLDS = false, bool STEP = BLOCK_SYNC, int VAR = -1>
 __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& sp, const double* __restrict__ theta, int B,
                                              double* __restrict__ wrec, int* __restrict__ wstat,
                                              int* __restrict__ wmode, double* __restrict__ wbase, int* __restrict__ slow_list,
@@ -313,6 +313,7 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
 #define LF_TST(i) do { } while (0)
 #endif
     LF_TST(0);
+    const int variant = VAR >= 0 ? VAR : kc.variant;      // (the persistent kernels know theirs at compile time)
     // TOLDS (lf_free's one-launch form, FREE): the records go to the tile's LDS arrays INSTEAD of memory - l_fc per (walker,
     // field) 8 doubles {alpha_C, V, cA, cY - H_LO - 1 / (2 H_INV), {mode, klo, khi, kne, kaC} as ints, cY - H_LO}, l_lf per
     // (walker, field) lF, l_sc per walker the 5 scalars, l_stat the status word, l_base the closed-form part of piece A: the
@@ -320,9 +321,41 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     const bool live = wq < B;
     const int w = live ? wq : B - 1;                 // idle groups replay the last walker, write nothing
     const bool has_f = f < kc.nf;
+    // This lane's field's constants.  The per-field arrays of the kernel's arguments are indexed by a lane number, so they are
+    // read from the argument segment by VECTOR loads (L2 hits: the scalar loads of warm_kernarg brought the lines in).  Left
+    // where they are used, each sits behind its own guard with its own wait - thirteen L2 round trips one after the other,
+    // ~6k cycles of the lone wave that prepares a tile (r03 stamps: 5k cycles between Q and the 8-lane combines for ~300
+    // instructions).  Here they are all issued together, in front of the row of theta, and waited for once.
+    struct {
+        double pmax, lum_min, lum_max, a_min, u_min, u_max, lnom0, slc, sp, som, flim0, z_lo, z_hi, sz, sz2;
+        int nsrc, kf_first, kf_last;
+    } kf;
+    // (ndim <= 16: two elements of the theta row per lane; a sampler's half-step makes its own row below)
+    const bool stepping = STEP && sp.enabled;
+    double t0 = 0.0, t1 = 0.0;
+    if (!stepping) {
+        const double* __restrict__ row = theta + (size_t)w * kc.ndim;
+        t0 = row[min(f, kc.ndim - 1)];
+        t1 = row[min(f + 8, kc.ndim - 1)];
+    }
+    kf.lum_min = kc.lum_min[f]; kf.lum_max = kc.lum_max[f]; kf.a_min = kc.a_min[f]; kf.slc = kc.slc[f]; kf.som = kc.som[f];
+    kf.nsrc = kc.nsrc[f];
+    if (variant == LF_ZEVOL) {
+        kf.z_lo = kc.z_lo[f]; kf.z_hi = kc.z_hi[f]; kf.sz = kc.sz[f]; kf.sz2 = kc.sz2[f];
+        kf.pmax = kf.u_min = kf.u_max = kf.lnom0 = kf.sp = kf.flim0 = 0.0; kf.kf_first = kf.kf_last = 0;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(kf.lum_min), "+v"(kf.lum_max), "+v"(kf.a_min), "+v"(kf.slc), "+v"(kf.som), "+v"(kf.nsrc),
+                          "+v"(kf.z_lo), "+v"(kf.z_hi), "+v"(kf.sz), "+v"(kf.sz2));
+    } else {
+        kf.pmax = kc.pmax[f]; kf.u_min = kc.u_min[f]; kf.u_max = kc.u_max[f]; kf.lnom0 = kc.lnom0_src[f]; kf.sp = kc.sp[f];
+        kf.flim0 = kc.flim0[f]; kf.kf_first = kc.kf_first[f]; kf.kf_last = kc.kf_last[f];
+        kf.z_lo = kf.z_hi = kf.sz = kf.sz2 = 0.0;
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(kf.lum_min), "+v"(kf.lum_max), "+v"(kf.a_min), "+v"(kf.slc), "+v"(kf.som), "+v"(kf.nsrc),
+                          "+v"(kf.pmax), "+v"(kf.u_min), "+v"(kf.u_max), "+v"(kf.lnom0), "+v"(kf.sp), "+v"(kf.flim0), "+v"(kf.kf_first),
+                          "+v"(kf.kf_last));
+    }
     // theta row of this walker -> LDS: either the given row, or the stretch-move proposal
     //   y = x_j - (x_j - x_k) z,   z = ((a - 1) u + 1)^2 / a,   j uniform in the other half
-    if (STEP && sp.enabled) {                        // (STEP: this instantiation may be handed the sampler's half-step)
+    if (stepping) {                                // (STEP: this instantiation may be handed the sampler's half-step)
         unsigned int rr[4];
         sampler_draw(sp.step, sp.half, w, 0, sp.seed, rr);
         const double z = stretch_z(sp.a, u53(rr[0], rr[1]));
@@ -340,10 +373,6 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             if (f == 0) l_zz[grp] = z;
         } else if (live && f == 0) sp.zz[w] = z;
     } else {
-        // (ndim <= 16: two elements per lane, both loads issued before either is waited for)
-        const double* __restrict__ row = theta + (size_t)w * kc.ndim;
-        double t0 = row[min(f, kc.ndim - 1)], t1 = row[min(f + 8, kc.ndim - 1)];
-        asm volatile("" : "+v"(t0), "+v"(t1));
         if (f < kc.ndim) sth[grp][f] = t0;
         if (f + 8 < kc.ndim) sth[grp][f + 8] = t1;
     }
@@ -356,7 +385,7 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     int neginf = 0, m = MODE_FAST;
     int cell_ok = 1;       // FREE: this lane's field may be summed over its cells (see below)
     double base = 0.0;     // this lane's share of the walker-only part of piece A (closed form)
-    if (kc.variant == LF_ZEVOL) {
+    if (variant == LF_ZEVOL) {
         const double L1 = th[0], L2 = th[1], L3 = th[2], p1 = th[3], p2 = th[4], p3 = th[5];
         const double al = kc.fix_sch_al ? kc.sch_al0 : th[6];
         if (!kc.fix_sch_al) ok = ok && (al >= kc.lims[LF_LIM_SCH_AL][0]) && (al <= kc.lims[LF_LIM_SCH_AL][1]);
@@ -369,6 +398,14 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
         quad_coef(L1, L2, L3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aL, bL, cL);
         quad_coef(p1, p2, p3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aP, bP, cP);
         const double c1 = LF_LN10 * (al + 1.0);
+        if (has_f && kf.nsrc > 0) {
+            // closed-form part: sum_i [ln Om_i + ln ln10 + ln10 phi*(z_i) + c1 (lum_i - L*(z_i))]; only
+            // -10^(lum_i - L*(z_i)) is left per source.  (First thing: the field's sums are not held in registers any longer.)
+            const double n = (double)kf.nsrc;
+            const double sph = aP * kf.sz2 + bP * kf.sz + n * cP;
+            const double sls = aL * kf.sz2 + bL * kf.sz + n * (cL - LF_LREF);
+            base = kf.som + n * LF_LNLN10 + LF_LN10 * sph + c1 * (kf.slc - sls);
+        }
         if (live && f == 0) {
             double* d = TOLDS ? l_sc + grp * 8 : r;
             d[Z_AL] = aL; d[Z_BL] = bL; d[Z_CL] = cL;
@@ -379,33 +416,27 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             // the local form of the term (srcsum_body) expands L*(z) about a lane's middle source: the size of its
             // exponent is bounded by this slope times the lane's width in z (a lane is narrower than 1 / 128 or the
             // chunk's key is 0 and the form is not taken)
-            const double s0 = fabs(fma(2.0 * aL, kc.z_lo[f], bL)), s1 = fabs(fma(2.0 * aL, kc.z_hi[f], bL));
+            const double s0 = fabs(fma(2.0 * aL, kf.z_lo, bL)), s1 = fabs(fma(2.0 * aL, kf.z_hi, bL));
             (TOLDS ? l_fc + (grp * MAXF + f) * 8 : r + RF(f, 0))[0] = LF_LN10 * (fmax(s0, s1) + fabs(aL) * (1.0 / 128.0));
             // the field's cells in redshift can stand for its sources (ZCELL_RHO above; NaN coefficients fail the test)
-            cell_ok = kc.nsrc[f] == 0 || (LF_LN10 * fmax(s0, s1) * kc.zcell_rho <= ZCELL_X1 &&
+            cell_ok = kf.nsrc == 0 || (LF_LN10 * fmax(s0, s1) * kc.zcell_rho <= ZCELL_X1 &&
                                           LF_LN10 * fabs(aL) * kc.zcell_rho * kc.zcell_rho <= ZCELL_X2);
         }
-        if (has_f && kc.nsrc[f] > 0) {
+        if (has_f && kf.nsrc > 0) {
             double lsmn, lsmx, phmn, phmx;
-            quad_range(aL, bL, cL, kc.z_lo[f], kc.z_hi[f], lsmn, lsmx);
-            quad_range(aP, bP, cP, kc.z_lo[f], kc.z_hi[f], phmn, phmx);
-            const double tmax = kc.lum_max[f] - lsmn, tmin = kc.lum_min[f] - lsmx;
+            quad_range(aL, bL, cL, kf.z_lo, kf.z_hi, lsmn, lsmx);
+            quad_range(aP, bP, cP, kf.z_lo, kf.z_hi, phmn, phmx);
+            const double tmax = kf.lum_max - lsmn, tmin = kf.lum_min - lsmx;
             // an UPPER bound of 10^tmax is all the test needs (single-precision hardware exp2, rounded up; NaN fails the test)
             const double vb = tmax < 2.9 ? (double)(__builtin_amdgcn_exp2f((float)tmax * 3.3219285f) * 1.0001f) + 1.0e-30 : 1.0e300;
             const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
-            m = (vb < 700.0 && lb > SAFE && lb + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
-            // closed-form part: sum_i [ln Om_i + ln ln10 + ln10 phi*(z_i) + c1 (lum_i - L*(z_i))]; only
-            // -10^(lum_i - L*(z_i)) is left per source
-            const double n = (double)kc.nsrc[f];
-            const double sph = aP * kc.sz2[f] + bP * kc.sz[f] + n * cP;
-            const double sls = aL * kc.sz2[f] + bL * kc.sz[f] + n * (cL - LF_LREF);
-            base = kc.som[f] + n * LF_LNLN10 + LF_LN10 * sph + c1 * (kc.slc[f] - sls);
+            m = (vb < 700.0 && lb > SAFE && lb + kf.a_min > SAFE) ? MODE_FAST : MODE_SLOW;
         }
     } else {
         const double Lstar = th[0], phistar = th[1];
         int k = 2;
         const double al = kc.fix_sch_al ? kc.sch_al0 : th[k++];
-        const double alphaC = kc.variant == LF_FREE ? th[k + kc.nf] : kc.alpha0;
+        const double alphaC = variant == LF_FREE ? th[k + kc.nf] : kc.alpha0;
         // inclusive box on all five named parameters, fixed ones too (lumfuncmcmc.py:346-354)
         ok = ok && (Lstar >= kc.lims[LF_LIM_LSTAR][0]) && (Lstar <= kc.lims[LF_LIM_LSTAR][1]);
         ok = ok && (phistar >= kc.lims[LF_LIM_PHISTAR][0]) && (phistar <= kc.lims[LF_LIM_PHISTAR][1]);
@@ -415,6 +446,12 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
         const double Q = exp10(LF_LREF - Lstar);
         asm volatile("" : "+v"(const_cast<double&>(Q)));
         LF_TST(2);
+        if (has_f && kf.nsrc > 0) {                 // (first thing: the field's sums are not held in registers any longer)
+            const double n = (double)kf.nsrc;
+            const double c0f = c0 + (variant == LF_FREE ? kf.lnom0 : 0.0);
+            base = n * c0f + c1 * (kf.slc - n * (Lstar - LF_LREF)) - Q * kf.sp +
+                   (variant == LF_FIXCOMP ? kf.som : 0.0);
+        }
         if (live && f == 0) {
             double* d = TOLDS ? l_sc + grp * 8 : r;
             d[R_LSTAR] = Lstar;
@@ -424,10 +461,10 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             d[R_ALPHAC] = alphaC;
         }
         if (has_f) {
-            const double Flim = kc.variant == LF_FREE ? th[k + f] : kc.flim0[f];
+            const double Flim = variant == LF_FREE ? th[k + f] : kf.flim0;
             ok = ok && (Flim >= kc.lims[LF_LIM_FLIM][0]) && (Flim <= kc.lims[LF_LIM_FLIM][1]);
             double lF = 0.0, V = 0.0;
-            if (kc.variant == LF_FREE) {
+            if (variant == LF_FREE) {
                 const double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
                 lF = log10(1.0e-17 * Flim);
                 V = 1.0 / (Flim * exp10(b));
@@ -447,7 +484,7 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                 }
                 // the field's cells can stand for its sources when all of them lie inside the tables for this walker
                 // (their width was chosen for the prior box's largest alpha_C: lfmcmc.hip, build_cells)
-                cell_ok = kc.nsrc[f] == 0 || (klo <= kc.kf_first[f] && kc.kf_last[f] <= khi);
+                cell_ok = kf.nsrc == 0 || (klo <= kf.kf_first && kf.kf_last <= khi);
                 if (live && TOLDS) {
                     double* d = l_fc + (grp * MAXF + f) * 8;
                     int* di = reinterpret_cast<int*>(d + 4);
@@ -474,14 +511,14 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                 }
             }
             LF_TST(3);
-            if (kc.nsrc[f] > 0) {
-                const double vmax = kc.pmax[f] * Q;       // the very product the kernels form for that source
-                const double tlo = kc.lum_min[f] - Lstar, thi = kc.lum_max[f] - Lstar;
+            if (kf.nsrc > 0) {
+                const double vmax = kf.pmax * Q;       // the very product the kernels form for that source
+                const double tlo = kf.lum_min - Lstar, thi = kf.lum_max - Lstar;
                 const double lbT = c0 + fmin(c1 * tlo, c1 * thi) - vmax;
                 if (vmax > LF_UNDERFLOW) {
                     m = MODE_NEGINF;
                     neginf = 1;
-                } else if (kc.variant == LF_FREE) {
+                } else if (variant == LF_FREE) {
                     // A LOWER bound of ln Omega of the field's faintest source is all the test needs, and the threshold is
                     // -700: elementary inequalities and single-precision hardware log instead of the device library's log, rsqrt
                     // and exp (this chain, on one wave, was a good part of the 7 us a tile's preparation took inside lf_free):
@@ -490,21 +527,17 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                     //   1 - e^-x >= x / (1 + x)                                   =>   ln fc / (1 - e^-x) >= ln fc (1 + 1 / x)
                     // (a NaN anywhere fails the comparisons: careful path.)  Looser than the exact value by at most ln 2 and a
                     // factor 1.3 - immaterial 700 e-folds away, and erring towards the careful path.
-                    const double num = alphaC * (kc.a_min[f] - lF);
+                    const double num = alphaC * (kf.a_min - lF);
                     const float an = (float)fmax(-num, 0.0);
                     const float lnfc_lo = num >= 0.0 ? -0.6932f
                                                      : -2.00002f * 0.69314724f * __builtin_amdgcn_logf(2.0f * (1.0f + an) * 1.000001f) - 0.01f;
-                    const float x = (float)(kc.u_min[f] * V) * 0.999999f;
-                    const double lnOm = kc.lnom0_src[f] + (double)(lnfc_lo * (1.0f + 1.000001f / x));
+                    const float x = (float)(kf.u_min * V) * 0.999999f;
+                    const double lnOm = kf.lnom0 + (double)(lnfc_lo * (1.0f + 1.000001f / x));
                     // fexp_neg takes |x| < 2^24 unclamped: screen the largest f / f_tau of the field as well
-                    m = (lbT > SAFE && lnOm > SAFE && lbT + lnOm > SAFE && kc.u_max[f] * V < 1.0e6) ? MODE_FAST : MODE_SLOW;
+                    m = (lbT > SAFE && lnOm > SAFE && lbT + lnOm > SAFE && kf.u_max * V < 1.0e6) ? MODE_FAST : MODE_SLOW;
                 } else {
-                    m = (lbT > SAFE && lbT + kc.a_min[f] > SAFE) ? MODE_FAST : MODE_SLOW;
+                    m = (lbT > SAFE && lbT + kf.a_min > SAFE) ? MODE_FAST : MODE_SLOW;
                 }
-                const double n = (double)kc.nsrc[f];
-                const double c0f = c0 + (kc.variant == LF_FREE ? kc.lnom0_src[f] : 0.0);
-                base = n * c0f + c1 * (kc.slc[f] - n * (Lstar - LF_LREF)) - Q * kc.sp[f] +
-                       (kc.variant == LF_FIXCOMP ? kc.som[f] : 0.0);
             }
         }
     }
@@ -518,8 +551,8 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     else if (neginf) m = MODE_SKIPSRC;
     const int slow = group8_or(has_f && m == MODE_SLOW ? 1 : 0);
     // cells: only walkers whose every field is FAST and inside the tables (all the others are rare, and summed per source)
-    const int nocell = group8_or(has_f && !(cell_ok && (m == MODE_FAST || kc.nsrc[f] == 0)) ? 1 : 0);
-    const int cells = kc.cells && (kc.variant == LF_FREE ? nqueue > 0 : kc.variant == LF_ZEVOL) && !bad && !neginf && !nocell;
+    const int nocell = group8_or(has_f && !(cell_ok && (m == MODE_FAST || kf.nsrc == 0)) ? 1 : 0);
+    const int cells = kc.cells && (variant == LF_FREE ? nqueue > 0 : variant == LF_ZEVOL) && !bad && !neginf && !nocell;
     if (live && has_f) {
         if (TOLDS) reinterpret_cast<int*>(l_fc + (grp * MAXF + f) * 8 + 4)[M_MODE] = m;
         else wmode[((size_t)w * MAXF + f) * WM + M_MODE] = m;

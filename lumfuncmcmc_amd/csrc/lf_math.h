@@ -228,15 +228,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // loads of fields indexed per lane).  BYTES = the size of the explicit arguments; the over-read up to the next multiple
 // of 256 stays inside the segment (the hidden arguments that follow are 256 bytes).
 // ----------------------------------------------------------------------------------------------
-#define LF_KW1(o) "s_load_dwordx16 %0, %1, " #o "\n\t"
+#define LF_KW1(o) "s_load_dword %0, %1, " #o "\n\t"
 #define LF_KW4(b) LF_KW1(b + 0x00) LF_KW1(b + 0x40) LF_KW1(b + 0x80) LF_KW1(b + 0xc0)
 template <int BYTES>
 __device__ __forceinline__ void warm_kernarg() {
-    typedef int v16i __attribute__((ext_vector_type(16)));
     constexpr int N4 = (BYTES + 255) / 256;
     static_assert(N4 >= 1 && N4 <= 10, "extend the ladder");
     auto p = __builtin_amdgcn_kernarg_segment_ptr();
-    v16i t;
+    int t;      // (one dword per 64-byte line: the line comes into the cache whatever the size of the load - and the cache's return
+                // path, shared by the 32 waves of two CUs that all do this at once, carries 4 bytes per line instead of 64)
     if constexpr (N4 == 1) asm volatile(LF_KW4(0x000) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
     if constexpr (N4 == 2) asm volatile(LF_KW4(0x000) LF_KW4(0x100) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");
     if constexpr (N4 == 3) asm volatile(LF_KW4(0x000) LF_KW4(0x100) LF_KW4(0x200) "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(p) : "memory");

@@ -103,7 +103,7 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
             const int pw = (int)(blockIdx.x >> 8) & 1;
             const int up = tid - 64 * pw;
             if (up >= 0 && up < 64) {
-                prepare_lane<false, true, STEP>(kc, sp, pa.theta, pa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w0 + (up >> 3), up & 7,
+                prepare_lane<false, true, STEP, VARIANT>(kc, sp, pa.theta, pa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w0 + (up >> 3), up & 7,
                                                 up >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, nullptr, nullptr, sprop, szz);
             } else if (!tables_loaded && tid >= 128 && tid < 128 + 256) {
                 const int t = tid - 128;

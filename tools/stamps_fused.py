@@ -65,11 +65,12 @@ def main():
 
     def q(x):
         return "median %7.0f  p10 %7.0f  p90 %7.0f  max %7.0f" % (np.median(x), np.percentile(x, 10), np.percentile(x, 90), x.max())
-    print("shader cycles (wave 0 of each workgroup), from the workgroup's start:")
+    print("shader cycles (wave 0 of each workgroup), from the wave's first instruction (lf_free) / after its arguments (lf_pers):")
     if ctx.last_launch()["kernel"].startswith("lf_free"):
         pk = out[:nb][out[:nb, 0] > 0][:, 2]
-        for i, name in enumerate(("theta in LDS", "Q = 10^(42 - L*) made", "records + keys written", "before the 8-lane combine")):
-            print("      preparation: %-26s" % name, q(((pk >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.int64) * 16))
+        for i, name in enumerate(("kernel arguments in", "entered (after the barrier)", "theta + field constants in", "Q = 10^(42 - L*) made",
+                                  "records + keys written")):
+            print("      preparation: %-26s" % name, q(((pk >> np.uint64(12 * i)) & np.uint64(0xfff)).astype(np.int64) * 16))
         print("    the preparing wave back         ", q(t_p0))
         print("    a table-loading wave done       ", q(t_tab))
     print("  tables + preparation + records  ", q(s[:, 3]))
