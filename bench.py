@@ -586,8 +586,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
-    ap.add_argument("--profile-every", type=int, default=10,
-                    help="bracket only every n-th evaluation of the timed steps with events (each pair stalls the stream ~8 us)")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="bracket only every n-th evaluation of the timed steps with events (each pair is two barrier packets and stalls "
+                         "the stream 8-12 us - most of an evaluation by now); 0 = as many as give two bracketed launches in the timed steps")
     args = ap.parse_args()
     if args.config:
         args.variant, args.nsrc, wtot, args.scaling = CONFIGS[args.config]
@@ -654,6 +655,8 @@ def main():
 
     leg = Leg(args, model, dev, local, world, rank, Wtot, shard)
     ctx, ndim, half = leg.ctx, leg.ndim, leg.half
+    if args.profile_every <= 0:
+        args.profile_every = max(args.steps, 1)                 # (two evaluations per step: two bracketed launches in the timed steps)
     dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level, agree=reduce_max, profile_every=args.profile_every)
     dt = reduce_max(dt)
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), "non-finite lnprob in the timed workload"

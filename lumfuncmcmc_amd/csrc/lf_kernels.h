@@ -330,6 +330,29 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
         double pmax, lum_min, lum_max, a_min, u_min, u_max, lnom0, slc, sp, som, flim0, z_lo, z_hi, sz, sz2;
         int nsrc, kf_first, kf_last;
     } kf;
+    // The prior box and the other scalars only the preparation reads, the same way (an index the compiler cannot see is zero
+    // makes the loads vector loads): as scalar arguments they were fetched by every wave in the kernel's preamble, parked in
+    // VGPR lanes and read back here lane by lane - ~100 of the lone wave's instructions, and two of the preamble's waits.
+    struct {
+        double lims[5][2], pivots[3], sch_al0, alpha0, fc_ratio, key_x0, zcell_rho;
+    } pc;
+    {
+        int vz = 0;
+        asm volatile("" : "+v"(vz));
+        const double* __restrict__ lp = &kc.lims[0][0];
+        const bool zv = variant == LF_ZEVOL;     // (what the other variant does not read stays 0 and costs no register)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) pc.lims[i >> 1][i & 1] = zv && (i >> 1) >= LF_LIM_FLIM ? 0.0 : lp[i + vz];
+        static_assert(LF_LIM_LSTAR < LF_LIM_FLIM && LF_LIM_PHISTAR < LF_LIM_FLIM && LF_LIM_SCH_AL < LF_LIM_FLIM && LF_LIM_ALPHA >= LF_LIM_FLIM,
+                      "the z-evolving variant's limits come first");
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pc.pivots[i] = zv ? (&kc.pivots[0])[i + vz] : 0.0;
+        pc.sch_al0 = (&kc.sch_al0)[vz];
+        pc.alpha0 = zv ? 0.0 : (&kc.alpha0)[vz];
+        pc.fc_ratio = zv ? 0.0 : (&kc.fc_ratio)[vz];
+        pc.key_x0 = zv ? 0.0 : (&kc.key_x0)[vz];
+        pc.zcell_rho = zv ? (&kc.zcell_rho)[vz] : 0.0;
+    }
     // (ndim <= 16: two elements of the theta row per lane; a sampler's half-step makes its own row below)
     const bool stepping = STEP && sp.enabled;
     double t0 = 0.0, t1 = 0.0;
@@ -353,6 +376,9 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                           "+v"(kf.pmax), "+v"(kf.u_min), "+v"(kf.u_max), "+v"(kf.lnom0), "+v"(kf.sp), "+v"(kf.flim0), "+v"(kf.kf_first),
                           "+v"(kf.kf_last));
     }
+    asm volatile("" : "+v"(pc.lims[0][0]), "+v"(pc.lims[0][1]), "+v"(pc.lims[1][0]), "+v"(pc.lims[1][1]), "+v"(pc.lims[2][0]), "+v"(pc.lims[2][1]),
+                      "+v"(pc.lims[3][0]), "+v"(pc.lims[3][1]), "+v"(pc.lims[4][0]), "+v"(pc.lims[4][1]), "+v"(pc.pivots[0]), "+v"(pc.pivots[1]),
+                      "+v"(pc.pivots[2]), "+v"(pc.sch_al0), "+v"(pc.alpha0), "+v"(pc.fc_ratio), "+v"(pc.key_x0), "+v"(pc.zcell_rho));
     // theta row of this walker -> LDS: either the given row, or the stretch-move proposal
     //   y = x_j - (x_j - x_k) z,   z = ((a - 1) u + 1)^2 / a,   j uniform in the other half
     if (stepping) {                                // (STEP: this instantiation may be handed the sampler's half-step)
@@ -387,16 +413,16 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     double base = 0.0;     // this lane's share of the walker-only part of piece A (closed form)
     if (variant == LF_ZEVOL) {
         const double L1 = th[0], L2 = th[1], L3 = th[2], p1 = th[3], p2 = th[4], p3 = th[5];
-        const double al = kc.fix_sch_al ? kc.sch_al0 : th[6];
-        if (!kc.fix_sch_al) ok = ok && (al >= kc.lims[LF_LIM_SCH_AL][0]) && (al <= kc.lims[LF_LIM_SCH_AL][1]);
+        const double al = kc.fix_sch_al ? pc.sch_al0 : th[6];
+        if (!kc.fix_sch_al) ok = ok && (al >= pc.lims[LF_LIM_SCH_AL][0]) && (al <= pc.lims[LF_LIM_SCH_AL][1]);
         const double Ls[3] = {L1, L2, L3}, ps[3] = {p1, p2, p3};
         for (int i = 0; i < 3; ++i) {           // strict for L and phi (lumfuncmcmc_z.py:355-358)
-            ok = ok && (Ls[i] > kc.lims[LF_LIM_LSTAR][0]) && (Ls[i] < kc.lims[LF_LIM_LSTAR][1]);
-            ok = ok && (ps[i] > kc.lims[LF_LIM_PHISTAR][0]) && (ps[i] < kc.lims[LF_LIM_PHISTAR][1]);
+            ok = ok && (Ls[i] > pc.lims[LF_LIM_LSTAR][0]) && (Ls[i] < pc.lims[LF_LIM_LSTAR][1]);
+            ok = ok && (ps[i] > pc.lims[LF_LIM_PHISTAR][0]) && (ps[i] < pc.lims[LF_LIM_PHISTAR][1]);
         }
         double aL, bL, cL, aP, bP, cP;
-        quad_coef(L1, L2, L3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aL, bL, cL);
-        quad_coef(p1, p2, p3, kc.pivots[0], kc.pivots[1], kc.pivots[2], aP, bP, cP);
+        quad_coef(L1, L2, L3, pc.pivots[0], pc.pivots[1], pc.pivots[2], aL, bL, cL);
+        quad_coef(p1, p2, p3, pc.pivots[0], pc.pivots[1], pc.pivots[2], aP, bP, cP);
         const double c1 = LF_LN10 * (al + 1.0);
         if (has_f && kf.nsrc > 0) {
             // closed-form part: sum_i [ln Om_i + ln ln10 + ln10 phi*(z_i) + c1 (lum_i - L*(z_i))]; only
@@ -419,8 +445,8 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             const double s0 = fabs(fma(2.0 * aL, kf.z_lo, bL)), s1 = fabs(fma(2.0 * aL, kf.z_hi, bL));
             (TOLDS ? l_fc + (grp * MAXF + f) * 8 : r + RF(f, 0))[0] = LF_LN10 * (fmax(s0, s1) + fabs(aL) * (1.0 / 128.0));
             // the field's cells in redshift can stand for its sources (ZCELL_RHO above; NaN coefficients fail the test)
-            cell_ok = kf.nsrc == 0 || (LF_LN10 * fmax(s0, s1) * kc.zcell_rho <= ZCELL_X1 &&
-                                          LF_LN10 * fabs(aL) * kc.zcell_rho * kc.zcell_rho <= ZCELL_X2);
+            cell_ok = kf.nsrc == 0 || (LF_LN10 * fmax(s0, s1) * pc.zcell_rho <= ZCELL_X1 &&
+                                          LF_LN10 * fabs(aL) * pc.zcell_rho * pc.zcell_rho <= ZCELL_X2);
         }
         if (has_f && kf.nsrc > 0) {
             double lsmn, lsmx, phmn, phmx;
@@ -435,13 +461,13 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     } else {
         const double Lstar = th[0], phistar = th[1];
         int k = 2;
-        const double al = kc.fix_sch_al ? kc.sch_al0 : th[k++];
-        const double alphaC = variant == LF_FREE ? th[k + kc.nf] : kc.alpha0;
+        const double al = kc.fix_sch_al ? pc.sch_al0 : th[k++];
+        const double alphaC = variant == LF_FREE ? th[k + kc.nf] : pc.alpha0;
         // inclusive box on all five named parameters, fixed ones too (lumfuncmcmc.py:346-354)
-        ok = ok && (Lstar >= kc.lims[LF_LIM_LSTAR][0]) && (Lstar <= kc.lims[LF_LIM_LSTAR][1]);
-        ok = ok && (phistar >= kc.lims[LF_LIM_PHISTAR][0]) && (phistar <= kc.lims[LF_LIM_PHISTAR][1]);
-        ok = ok && (al >= kc.lims[LF_LIM_SCH_AL][0]) && (al <= kc.lims[LF_LIM_SCH_AL][1]);
-        ok = ok && (alphaC >= kc.lims[LF_LIM_ALPHA][0]) && (alphaC <= kc.lims[LF_LIM_ALPHA][1]);
+        ok = ok && (Lstar >= pc.lims[LF_LIM_LSTAR][0]) && (Lstar <= pc.lims[LF_LIM_LSTAR][1]);
+        ok = ok && (phistar >= pc.lims[LF_LIM_PHISTAR][0]) && (phistar <= pc.lims[LF_LIM_PHISTAR][1]);
+        ok = ok && (al >= pc.lims[LF_LIM_SCH_AL][0]) && (al <= pc.lims[LF_LIM_SCH_AL][1]);
+        ok = ok && (alphaC >= pc.lims[LF_LIM_ALPHA][0]) && (alphaC <= pc.lims[LF_LIM_ALPHA][1]);
         const double c0 = LF_LNLN10 + LF_LN10 * phistar, c1 = LF_LN10 * (al + 1.0);
         const double Q = exp10(LF_LREF - Lstar);
         asm volatile("" : "+v"(const_cast<double&>(Q)));
@@ -462,10 +488,10 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
         }
         if (has_f) {
             const double Flim = variant == LF_FREE ? th[k + f] : kf.flim0;
-            ok = ok && (Flim >= kc.lims[LF_LIM_FLIM][0]) && (Flim <= kc.lims[LF_LIM_FLIM][1]);
+            ok = ok && (Flim >= pc.lims[LF_LIM_FLIM][0]) && (Flim <= pc.lims[LF_LIM_FLIM][1]);
             double lF = 0.0, V = 0.0;
             if (variant == LF_FREE) {
-                const double b = -sqrt(kc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
+                const double b = -sqrt(pc.fc_ratio / (alphaC * alphaC));     // VmaxLumFunc.py:165
                 lF = log10(1.0e-17 * Flim);
                 V = 1.0 / (Flim * exp10(b));
                 const double cA = -alphaC * lF, cY = -(lF + b);
@@ -477,9 +503,9 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
                     const double xlo = fmax((G_NUM_LO + 2.0 * G_MARGIN - cA) / alphaC, H_LO + 2.0 * H_MARGIN - cY);
                     const double xhi = (G_NUM_HI - 2.0 * G_MARGIN - cA) / alphaC;
                     const double xne = 1.5740312677277188 - cY;            // log10(37.5)
-                    klo = key_ceil((xlo - kc.key_x0) * KEY_SCALE);
-                    khi = key_floor((xhi - kc.key_x0) * KEY_SCALE);
-                    kne = key_ceil((xne - kc.key_x0) * KEY_SCALE);
+                    klo = key_ceil((xlo - pc.key_x0) * KEY_SCALE);
+                    khi = key_floor((xhi - pc.key_x0) * KEY_SCALE);
+                    kne = key_ceil((xne - pc.key_x0) * KEY_SCALE);
                     kac = key_ceil(alphaC * KEY_ASCALE);
                 }
                 // the field's cells can stand for its sources when all of them lie inside the tables for this walker
