@@ -34,14 +34,13 @@ constexpr int QSTRIDE = 9;   // counters per tile: [0] grid queue, [1..8] catalo
 constexpr int VF = 32;
 // The deal table: [0 .. VF] where rank vr's cell chunks start in the list, [VF + 1 .. 2 VF + 1] the same for its bins, then the
 // list (cell chunks rank by rank, then bins rank by rank).  Who gets what is decided by COST: a flux bin costs a wave about
-// 2.7 cell chunks, and the workgroups of ranks >= VF / 2 are the younger ones of their CUs, ~1.3 cell chunks behind their
-// elders when the sums begin (tools/stamps_fused.py) - the host deals bins, then cells, each to the rank that would be done
-// first.  With the arithmetic deal (bin c to rank c mod VF, cell chunk cc to rank (cc + VF / 2) mod VF) the busiest rank of the
+// 2.7 cell chunks, and the workgroups of ranks >= VF / 2 are the younger ones of their CUs, behind their elders when the sums
+// begin (tools/stamps_fused.py) - the host deals bins, then cells, each to the rank that would be done first (lfmcmc.hip:
+// ensure_deal has the costs and the sweep they come from).  With the arithmetic deal (bin c to rank c mod VF, cell chunk cc to rank (cc + VF / 2) mod VF) the busiest rank of the
 // benchmark's context had a bin and two cell chunks (10.4k cycles), the average being 6.6k, and the 17th bin sat on a younger
 // rank with two cell chunks of its own.  A context's table depends on its numbers of bins and cell chunks only: a row's
 // partial sums (one per virtual rank) are the same whatever the batch.
 constexpr int DEAL_BINS = VF + 1, DEAL_LIST = 2 * (VF + 1), DEAL_MAX = 512;
-constexpr int TOUCH_PER = 4;          // touches per lane and rank (256 lines = 32 KB: three cell chunks and a bin of 30 rows)
 
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
 // (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
@@ -79,7 +78,7 @@ struct FreeArgs {
     const int* deal;          // the static deal of cell chunks and flux bins to the VF virtual workgroups (DEAL_* below; made by the
                               // host from the chunks' costs: lfmcmc.hip, ensure_deal) or NULL = the arithmetic deal
     const int* cc_len;        // [nchC] its cells (<= 64: one per lane of a wave; the waves take one walker each)
-    const int* touch;         // [VF][TOUCH_PER][64] the 128-byte lines rank vr's workgroup touches ahead (buffer << 28 | line; -1 none), or NULL
+    const int* cc_field;      // [nchC]
     int nchC;                 // cell chunks (64 cells; 0: no cells)
     double* partC;            // [B][nslot]: the cells' sums, likewise
     const int* wstat;         // [B]
@@ -225,7 +224,6 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
         };
         if (tile != ((int)blockIdx.x >> 3) % fa.ntiles) __syncthreads();      // the previous tile's last reads of wfc / wsc / sitem are done
         const int u = fresh_tid();
-        int touched[2 * TOUCH_PER] = {};                   // (see the prologue's touches)
         if (FUSED) {
             // Wave 0 prepares the tile's 8 walkers (lf_prepare's body) and puts their records straight into LDS (wfc, wsc,
             // wlf, sstat, sbase: the one-launch form writes no records to memory - the launch that makes them is the only
@@ -270,40 +268,6 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
 #ifdef LF_STAMPS
                 if (t7 == 0) s_ttab = __builtin_amdgcn_s_memtime();
 #endif
-                // One of these waves, idle until the preparing wave is back: TOUCH what this workgroup's ranks will read after
-                // the barrier - their cell chunks, their bins' records and the bins' row weights - one dword per 128-byte
-                // line, so that the lines are in this XCD's L2 by then.  Nothing of a launch's inputs is in a cache when it
-                // starts, a wave holds one chunk ahead at most, and a trip to memory is ~2k cycles: a rank with three cell
-                // chunks spent 10k cycles on them (3.4k per chunk for 0.7k of arithmetic), a bin 6.7k.  The rank's entries
-                // of the deal table come by scalar loads (the table itself is only on its way to LDS).  The values go
-                // nowhere: the sink below, behind the barrier, keeps the loads where they are.
-                if (t7 >= 320 && t7 < 384 && fa.touch) {
-                    // (the lines come from a table the host made with the deal: one entry per lane and slot, two round trips in
-                    // all - the entries, then the touches, all of them in flight together; the first two of the workgroup's ranks)
-                    const int ln = t7 - 320;
-                    int e[2][TOUCH_PER];
-                    // (the three buffers' addresses as opaque scalars: left to itself the compiler picks the pointer by a VECTOR load
-                    // from the argument segment, indexed by the entry's buffer number - and every touch waits for its own)
-                    unsigned long long pb0 = reinterpret_cast<unsigned long long>(fa.cells), pb1 = reinterpret_cast<unsigned long long>(fa.gq_rec),
-                                       pb2 = reinterpret_cast<unsigned long long>(fa.gq_omega), pbn = reinterpret_cast<unsigned long long>(fa.touch);
-                    asm volatile("" : "+s"(pb0), "+s"(pb1), "+s"(pb2), "+s"(pbn));
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int i = 0; i < TOUCH_PER; ++i) e[k][i] = fa.touch[(min(frank + k * fgroup, VF - 1) * TOUCH_PER + i) * 64 + ln];
-                    static_assert(TOUCH_PER == 4, "the pin below");
-                    asm volatile("" : "+v"(e[0][0]), "+v"(e[0][1]), "+v"(e[0][2]), "+v"(e[0][3]), "+v"(e[1][0]), "+v"(e[1][1]), "+v"(e[1][2]), "+v"(e[1][3]));
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int i = 0; i < TOUCH_PER; ++i) {
-                            const int b = e[k][i] >> 28;
-                            const bool have = e[k][i] >= 0 && frank + k * fgroup < VF;
-                            const unsigned long long at = have ? (b == 0 ? pb0 : b == 1 ? pb1 : pb2) + (unsigned long long)(e[k][i] & 0x0fffffff) * 128ull : pbn;
-                            typedef const int __attribute__((address_space(1))) global_int;      // (a global load, not a flat one)
-                            touched[TOUCH_PER * k + i] = *reinterpret_cast<global_int*>(at);
-                        }
-                }
             }
             if (STEP && u >= PB - 64 && u < PB - 64 + nw) {
                 // (the last wave, idle once its share of the tables is on its way: the accept step's logarithms, from the same
@@ -316,8 +280,6 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             }
             tables_loaded = true;
             __syncthreads();
-            asm volatile("" :: "v"(touched[0]), "v"(touched[1]), "v"(touched[2]), "v"(touched[3]), "v"(touched[4]), "v"(touched[5]), "v"(touched[6]),
-                         "v"(touched[7]));
         }
         if (u < 64) {
             // which walkers of the tile lf_prepare put on the cells (one load per lane); when all of them are, the sources

@@ -67,7 +67,6 @@ struct lf_ctx {
     int* d_cc_start = nullptr;           // [ncchunk] first cell of the chunk
     int* d_deal = nullptr;               // lf_free's deal of cell chunks and flux bins to its virtual workgroups (lf_free.h: DEAL_*)
     int64_t deal_key = -1;               // ... made for this (cell chunks, bins, grid share)
-    int* d_touch = nullptr;              // [VF][TOUCH_PER][64]: the lines a rank's workgroup touches ahead (lf_free.h: the prologue's touches)
     int* d_cc_len = nullptr;             // [ncchunk] cells in the chunk (<= 64)
     int* d_cc_field = nullptr;           // [ncchunk]
     int ncell = 0, ncchunk = 0;
@@ -109,7 +108,6 @@ struct lf_ctx {
         double margin = 0.0;
         double *d_rec = nullptr, *d_omega = nullptr;
         int* d_rows = nullptr;
-        std::vector<int> h_rows;        // host copy of d_rows ({row0, nrows, offset into omega, -} per bin)
     } gridq;
     int64_t opt_grid_shortcut = 1;      // 0: lf_free integrates the lattice (A/B runs)
     // FIXCOMP, ZEVOL: the grid's nodes as 32-byte records {G, PG, W, column} padded to chunks of 64, and the columns' redshifts
@@ -601,24 +599,27 @@ int free_groups(lf_ctx* c, int slot, int ntiles, int nchA, int nchB, int nchC) {
 }
 
 // lf_free's static deal (lf_free.h: DEAL_*): flux bins, then cell chunks, each to the virtual workgroup that would be done
-// first - a bin costs a wave 8 units, a cell chunk 3, and the ranks of the younger half start 4 units behind (measured:
-// tools/stamps_fused.py).  Bins that a source-sharded rank does not integrate (grid_share) cost nothing.  The table depends
+// first - a bin costs a wave 8 units, a cell chunk 3 (tools/stamps_fused.py), and the ranks of the younger half are
+// counted 8 units behind (swept on one box, tools/deal_sweep.sh: 13.4 us per 128-row evaluation at 8-10, 13.75 at 0-6,
+// 14.0 at 16; the arithmetic deal 15.25; at 256 rows, where a workgroup serves an elder and a younger rank, all within 2 %).  Bins that a source-sharded rank does not integrate (grid_share) cost nothing.  The table depends
 // on the context (numbers of cell chunks and bins, grid share) only - never on the batch.  No table (the arithmetic deal):
 // no bins, or more entries than the kernel keeps in LDS.
 int ensure_deal(lf_ctx* c, int nchC, int nbq, hipStream_t s) {
     using namespace lf;
-    const int64_t key = nbq <= 0 || DEAL_LIST + nchC + nbq > DEAL_MAX
+    const int64_t key = nbq <= 0 || DEAL_LIST + nchC + nbq > DEAL_MAX || std::getenv("LF_NO_DEAL")      // (the variable: A/B runs)
                             ? 0 : 1 + nchC + 4096ll * nbq + (4096ll * 4096) * (c->kc.grid_part + 4096ll * c->kc.grid_parts);
     if (key == c->deal_key) return LF_OK;
     if (key > 0) {
         std::vector<int> load(VF), cnt_c(VF, 0), cnt_b(VF, 0), own_c(nchC), own_b(nbq);
-        for (int v = 0; v < VF; ++v) load[v] = v >= VF / 2 ? 4 : 0;
+        const int cost_h = std::getenv("LF_DEAL_H") ? std::atoi(std::getenv("LF_DEAL_H")) : 8;       // (tuning runs: tools/deal_sweep.sh)
+        const int cost_b = std::getenv("LF_DEAL_B") ? std::atoi(std::getenv("LF_DEAL_B")) : 8;
+        for (int v = 0; v < VF; ++v) load[v] = v >= VF / 2 ? cost_h : 0;
         auto next = [&]() { return (int)(std::min_element(load.begin(), load.end()) - load.begin()); };      // (ties: the lowest rank)
         for (int b = 0; b < nbq; ++b) {
             const int v = next();
             own_b[b] = v;
             ++cnt_b[v];
-            load[v] += c->kc.grid_parts > 1 && b % c->kc.grid_parts != c->kc.grid_part ? 0 : 8;
+            load[v] += c->kc.grid_parts > 1 && b % c->kc.grid_parts != c->kc.grid_part ? 0 : cost_b;
         }
         for (int i = 0; i < nchC; ++i) {
             const int v = next();
@@ -636,27 +637,9 @@ int ensure_deal(lf_ctx* c, int nchC, int nbq, hipStream_t s) {
         std::vector<int> at_c(t.begin(), t.begin() + VF), at_b(t.begin() + DEAL_BINS, t.begin() + DEAL_BINS + VF);
         for (int i = 0; i < nchC; ++i) t[DEAL_LIST + at_c[own_c[i]]++] = i;
         for (int b = 0; b < nbq; ++b) t[DEAL_LIST + nchC + at_b[own_b[b]]++] = b;
-        // ... and what each rank will read, as 128-byte lines for its workgroup to touch ahead (one list entry per lane and slot:
-        // buffer << 28 | line; -1 = none): its cell chunks (40 lines apiece), its bins' records (16) and row weights (4 per row)
-        std::vector<int> touch((size_t)VF * TOUCH_PER * 64, -1);
-        for (int v = 0; v < VF; ++v) {
-            int n = 0;
-            auto add = [&](int buf, size_t byte0, size_t bytes) {
-                for (size_t l = byte0 / 128; l <= (byte0 + bytes - 1) / 128 && n < TOUCH_PER * 64; ++l) touch[(size_t)v * TOUCH_PER * 64 + n++] = (buf << 28) | (int)l;
-            };
-            for (int i = t[v]; i < t[v + 1]; ++i) add(0, (size_t)t[DEAL_LIST + i] * 64 * CELL_REC * 8, (size_t)64 * CELL_REC * 8);
-            for (int i = t[DEAL_BINS + v]; i < t[DEAL_BINS + v + 1]; ++i) {
-                const int b = t[DEAL_LIST + nchC + i];
-                if (c->kc.grid_parts > 1 && b % c->kc.grid_parts != c->kc.grid_part) continue;
-                add(1, (size_t)b * 64 * 4 * 8, (size_t)64 * 4 * 8);
-                add(2, (size_t)c->gridq.h_rows[4 * b + 2] * 8, (size_t)c->gridq.h_rows[4 * b + 1] * 64 * 8);
-            }
-        }
         if (!c->d_deal) LF_HIP(c, hipMalloc((void**)&c->d_deal, (size_t)DEAL_MAX * sizeof(int)));
-        if (!c->d_touch) LF_HIP(c, hipMalloc((void**)&c->d_touch, touch.size() * sizeof(int)));
         if (c->any_enqueued) LF_HIP(c, hipStreamSynchronize(c->last_stream));        // (a launch may still be reading the old table)
         LF_HIP(c, hipMemcpy(c->d_deal, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
-        LF_HIP(c, hipMemcpy(c->d_touch, touch.data(), touch.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     c->deal_key = key;
     return LF_OK;
@@ -729,7 +712,7 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     const SrcArrays sa{c->d_lum, c->d_a1, c->d_P, c->d_U, nullptr, ct->d_start, ct->d_len, ct->d_field, ct->d_keys, nullptr};
     const NodeArrays na{c->d_G, c->d_PG, c->d_W, c->d_a3, c->d_a4, c->d_a4min, c->nnodes};
     FreeArgs fa{B, ntiles, nchA, nchB, nslot, g8, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
-                c->d_cells, c->d_nodes8, c->deal_key > 0 ? c->d_deal : nullptr, c->d_cc_len, c->deal_key > 0 ? c->d_touch : nullptr, nchC, c->d_partR, c->d_wstat,
+                c->d_cells, c->d_nodes8, c->deal_key > 0 ? c->d_deal : nullptr, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat,
                 d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat, c->d_wbase,
                 gq ? c->gridq.d_rec : nullptr, gq ? c->gridq.d_omega : nullptr, gq ? c->gridq.d_rows : nullptr, gq ? c->gridq.nb : 0};
     {
@@ -1187,7 +1170,6 @@ void free_ctx(lf_ctx* c) {
     if (c->d_cells) hipFree(c->d_cells);
     if (c->d_cc_start) hipFree(c->d_cc_start);
     if (c->d_deal) hipFree(c->d_deal);
-    if (c->d_touch) hipFree(c->d_touch);
     if (c->d_cc_len) hipFree(c->d_cc_len);
     if (c->d_cc_field) hipFree(c->d_cc_field);
     {
@@ -1446,7 +1428,6 @@ int build(lf_ctx* c, const lf_desc* d) {
                     if ((rc = upload(c, &g.d_rec, gq.rec.data(), gq.rec.size())) != LF_OK) return rc;
                     if ((rc = upload(c, &g.d_omega, gq.omega.data(), gq.omega.size())) != LF_OK) return rc;
                     if ((rc = upload(c, &g.d_rows, gq.rows.data(), gq.rows.size())) != LF_OK) return rc;
-                    g.h_rows.assign(gq.rows.begin(), gq.rows.end());
                     g.nb = gq.nb;
                     g.margin = gq.margin;
                     g.built = true;

@@ -64,7 +64,7 @@ def test_persistent_kernel_of_the_other_variants_fits_two_workgroups_per_cu(rema
         for name, r in _find(remarks, prefix).items():
             # (the sampler's half-step keeps the accept step's arguments alive across the whole kernel: a few values are parked
             # in scratch in its preamble and fetched back in its epilogue - never inside the loops)
-            assert r["VGPRs"] <= 128 and r["ScratchSize"] <= (160 if "_step" in prefix else 0), (name, r)
+            assert r["VGPRs"] <= 128 and r["ScratchSize"] <= (192 if "_step" in prefix else 0), (name, r)
             assert r["LDS Size"] <= 80 * 1024, (name, r)
 
 
