@@ -266,12 +266,8 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
                 auto mine = [&](int c) { return !(kc.grid_parts > 1 && c % kc.grid_parts != kc.grid_part); };
                 const double c1 = uni(sc[VARIANT == LF_ZEVOL ? Z_C1 : R_C1]);
                 const double Ls = uni(sc[R_LSTAR]), c0 = uni(sc[R_C0]), Qf = uni(sc[R_Q]);      // (FIXCOMP)
-                Node nx = load_nodes(clo);
-#pragma unroll 1
-                for (int c = clo; c < chi; ++c) {
-                    const Node nd = nx;
-                    if (c + 1 < chi) nx = load_nodes(c + 1);
-                    if (!mine(c)) continue;
+                auto node = [&](const Node& nd, int c) {
+                    if (!mine(c)) return;
                     asm volatile("; LF_BEGIN pznode items=1");
                     double e;
                     if (VARIANT == LF_ZEVOL) {
@@ -282,9 +278,25 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
                         e = fma(c1, nd.G - Ls, c0) - nd.PG * Qf;
                     }
                     // (a chunk whose every node has underflowed - the bright end of the grid, 10^(L - L*) > 750 - adds exact zeros)
-                    if (__ballot(e > -750.0) == 0ull) continue;
-                    bsum = fma(nd.W, fexp_c(e, &tab), bsum);
+                    if (__ballot(e > -750.0) != 0ull) bsum = fma(nd.W, fexp_c(e, &tab), bsum);
                     asm volatile("; LF_END pznode");
+                };
+                // One chunk ahead, in two sets of registers used in turn (the loop does two chunks per trip).  Written with one
+                // set and a copy - nd = nx; nx = the next chunk - the compiler waited for the next chunk's loads at the END of
+                // the trip that issued them, to make the copy: nothing was ahead, and a trip took a trip to L2 (720 cycles
+                // for 90 of issue, four waves to a SIMD: tools/stamps_fused.py; 14.4k -> 12.4k cycles for the phase).  The loads
+                // unconditional - past the run's end the last chunk again: behind a branch the compiler cannot count the loads in
+                // flight, and waits for all of them.  (Three sets, two chunks ahead: measured the same.  The cells' loop above
+                // has the same shape, but written this way its second set of 16 registers cost the grid's loop more than the
+                // cells gained: 17.95 against 17.5 us per evaluation; so did touching the cells ahead, from the prologue or from
+                // here with the cells' phase moved behind the grid's.)
+                Node na = load_nodes(clo), nb;
+#pragma unroll 1
+                for (int c = clo; c < chi; c += 2) {
+                    nb = load_nodes(min(c + 1, chi - 1));
+                    node(na, c);
+                    na = load_nodes(min(c + 2, chi - 1));
+                    if (c + 1 < chi) node(nb, c + 1);
                 }
             }
             bsum = wave_sum_dpp(bsum);
