@@ -111,3 +111,34 @@ def test_a_box_without_proven_bins_keeps_the_lattice():
     with np.errstate(all="ignore"):
         ref = O.lnprob_batch(inp, th)
     compare_rows(lp, ref, inp, th, 1e-12)
+
+
+@pytest.mark.parametrize("n,rows", [(1000000, 128), (1000000, 300), (100003, 40), (1000, 16)])
+def test_the_dealt_chunks_equal_the_arithmetic_deal(n, rows, monkeypatch):
+    """lf_free deals its cell chunks and flux bins to the virtual workgroups by a host-made table (lfmcmc.hip: ensure_deal;
+    lf_free.h: DEAL_*), or arithmetically (LF_NO_DEAL: the A/B switch): the same chunks, each exactly once, in another order
+    of summation - and with the table, too, one row at a time gives the batch's bits"""
+    from lumfuncmcmc_amd.capi import LFContext
+    inp = make_inputs("free", n, seed=141)
+    ctx = LFContext(inp, max_batch=max(rows, 64))
+    ctx.set_option("persistent", 2)
+    th = _rows(rows, 142)
+    th[7, 0] = 40.2
+    th[9, 1] = 6.0
+    a1, b1 = ctx.lnprob_pieces(th)
+    lp1 = ctx.lnprob_batch(th)
+    one = np.array([ctx.lnprob_batch(th[i:i + 1])[0] for i in range(0, rows, 7)])
+    monkeypatch.setenv("LF_NO_DEAL", "1")
+    a0, b0 = ctx.lnprob_pieces(th)
+    lp0 = ctx.lnprob_batch(th)
+    monkeypatch.delenv("LF_NO_DEAL")
+    lp2 = ctx.lnprob_batch(th)                     # back on the table
+    ctx.close()
+    np.testing.assert_array_equal(lp2, lp1)
+    np.testing.assert_array_equal(one, lp1[::7])
+    assert np.array_equal(np.isinf(lp1), np.isinf(lp0))
+    fin = np.isfinite(lp0)
+    np.testing.assert_allclose(lp1[fin], lp0[fin], rtol=2e-15)
+    ok = np.isfinite(a0) & np.isfinite(a1)
+    np.testing.assert_allclose(a1[ok], a0[ok], rtol=2e-15)
+    np.testing.assert_allclose(b1[ok], b0[ok], rtol=2e-15)
