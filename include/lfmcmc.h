@@ -178,6 +178,11 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * and the walker-sharded sampler's halves always take three).  "fuse_step": 1 (default) makes a half-step of the
  * device-resident sampler ONE launch of the same kernels (proposal in the prologue, accept / reject and the chain's row
  * by the tile's finishing workgroup); 0 = lf_propose+prepare, kernel, lf_finalize+accept (same chain, bit for bit).
+ * "poll": 1 (default) lets a tile of the one-launch form whose walkers need no per-source sums (the normal case) hand its
+ * partial sums over by POLLING: every slot of the partial-sum buffers is kept at a reserved NaN pattern between launches,
+ * a workgroup writes its sums through and is done, and the tile's finishing workgroup reads the slots until none is
+ * empty (at most 2^19 times: then it writes NaN and lf_lnprob_batch returns LF_ERR_HIP); 0 = every tile counts its
+ * workgroups (store, wait for the acknowledgement, atomic counter; A/B runs).  Same sums in the same order: same bits.
  * "profile_every": see lf_set_profiling.
  * "grid_shortcut": 1 (default) lets lf_free take piece B of a FREE context whose integration grid is separable (every
  * redshift column has the same luminosity nodes: min_comp_frac = 0) over FLUX BINS instead of the S^2 lattice points: the

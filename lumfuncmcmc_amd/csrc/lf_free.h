@@ -41,6 +41,15 @@ constexpr int VF = 32;
 // rank with two cell chunks of its own.  A context's table depends on its numbers of bins and cell chunks only: a row's
 // partial sums (one per virtual rank) are the same whatever the batch.
 constexpr int DEAL_BINS = VF + 1, DEAL_LIST = 2 * (VF + 1), DEAL_MAX = 512;
+// The one-launch form's hand-over by POLLING (tiles whose walkers are all on the cells: the normal case).  The slots of partB /
+// partC hold PART_EMPTY between launches (the host fills them, every finisher leaves them so); a workgroup writes its partial
+// sums through and is done; the tile's FINISHER - the workgroup of the last physical rank, the lightest of the deal - reads the
+// slots past its caches until none is empty, adds them up and empties them again.  Against the counter (every workgroup:
+// wait for the stores' acknowledgements, count, wait for the count; the last one: load, add) the launch's critical path
+// loses two of its three trips to memory.  A partial sum is never PART_EMPTY (a NaN is made canonical before it is stored);
+// a finisher that has polled PART_POLLS times without success writes NaN (emcee raises on NaN) and sets the error word.
+constexpr unsigned long long PART_EMPTY = 0x7ff8dead7ff8deadull;
+constexpr int PART_POLLS = 1 << 19;
 
 // 512-thread block reduction: red[nw][512] -> out[(w0 + w) * stride + chunk], nw <= 8: wave w adds walker w's row
 // (eight columns per lane, stride 64) and runs one 64-lane sum on the DPP network.  Fixed order.
@@ -95,6 +104,8 @@ struct FreeArgs {
     const double* gq_omega;   // per bin [row][64]: the rows' quadrature weights, trapezoid weights folded in
     const int* gq_rows;       // [nbq][4] {row0, nrows (<= 64), offset into gq_omega, -}
     int nbq;
+    int poll;                 // 1: the slots of partB / partC are PART_EMPTY (the host's word): tiles without source work hand over by polling
+    int* err;                 // error word (a finisher gave up polling)
 };
 
 // CENSUS: the instantiation that counts which form of the term ran (lf_form_counts); the product one has no trace of it
@@ -118,7 +129,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
     // is written THROUGH this XCD's L2 (a relaxed store of agent scope: scope bits on the one store - no cache-wide
     // write-back or invalidate, which is what a fence of that scope costs: measured 154 us per evaluation instead of 30)
     auto pstore = [](double* p, double v) {
-        if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FUSED) __hip_atomic_store(p, v == v ? v : __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (never PART_EMPTY)
         else *p = v;
     };
     __shared__ MathTables tab;
@@ -129,6 +140,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
     __shared__ int sitem[2];
     __shared__ int sdeal[DEAL_MAX];        // the deal table (fa.deal), with the tables
     __shared__ int scell;                  // bit w: walker w of the tile is summed over the cells
+    __shared__ int snosrc;                 // the tile has no source work at all (every live walker on the cells)
     const int tid = threadIdx.x;
     __shared__ int sstat[PTW];             // FUSED: the tile's status words, straight from the preparation
     __shared__ double sbase[PTW];          //        ... the closed-form part of piece A
@@ -295,6 +307,7 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             if (u == 0) {
                 scell = m;
                 no_src = mneed == 0ull;
+                snosrc = no_src ? 1 : 0;
                 sitem[0] = grab();
             }
         }
@@ -726,12 +739,43 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
             }
 #endif
         }
-        if (FUSED) {
+        if (FUSED && fa.poll && uni(snosrc)) {
+            // Hand-over by polling (PART_EMPTY above): this workgroup's partial sums are on their way, written through; only
+            // the tile's finisher has more to do.
+            if (frank == fgroup - 1) {
+                const int t = fresh_tid(), v = t >> 6, ln = t & 63;
+                const int nB = fa.nchB > 0 ? fa.nslot : 0, nC = fa.nchC > 0 ? fa.nslot : 0;
+                if (v < nw) {
+                    double* __restrict__ pb = fa.partB + (size_t)(w0 + v) * fa.nslot;
+                    double* __restrict__ pc = fa.partC + (size_t)(w0 + v) * fa.nslot;
+                    double pre[2] = {0.0, 0.0};
+                    int tries = 0;
+                    bool have;
+                    do {
+                        if (ln < nC) pre[0] = __hip_atomic_load(pc + ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ln < nB) pre[1] = __hip_atomic_load(pb + ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        have = !((ln < nC && (unsigned long long)__double_as_longlong(pre[0]) == PART_EMPTY) ||
+                                 (ln < nB && (unsigned long long)__double_as_longlong(pre[1]) == PART_EMPTY));
+                    } while (!__all(have) && ++tries < PART_POLLS);
+                    if (tries >= PART_POLLS) {        // (cannot happen while the device runs the launch's other workgroups)
+                        pre[0] = pre[1] = __builtin_nan("");
+                        if (ln == 0) atomicExch(fa.err, 1);
+                    }
+                    // the slots empty again for the next launch (visible to it: a kernel boundary lies between)
+                    if (ln < nC) __hip_atomic_store(pc + ln, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ln < nB) __hip_atomic_store(pb + ln, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    finalize_wave<true>(fa.partA, 0, fa.nchA, fa.partB, nB, nB, nC > 0 ? fa.partC : nullptr, nC, (int)STAT_CELLS,
+                                        sstat - w0, sbase - w0, w0 + v, ln, ap, fa.out, nullptr, nullptr, 0,
+                                        STEP ? sprop + v * 16 : nullptr, STEP ? szz + v : nullptr, STEP ? spre + 2 * v : nullptr, pre);
+                }
+            }
+        } else if (FUSED) {
             // This workgroup's partial sums are out - written through, and complete once its waves have waited for their
             // stores' acknowledgements (the explicit s_waitcnt: the compiler does not emit one for a workgroup-scope fence,
             // and the count must not overtake a partial sum on its way to memory); the count (an atomic of agent scope)
             // comes after the barrier.  The last of the tile's workgroups to count adds the partials up,
             // reading them from memory (finalize_wave<true>); the walkers' records it needs are its own copies.
+            // (Tiles with source work: their per-chunk sums have no fixed writer to poll for.)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (every wave: its write-through stores have been acknowledged)
             __threadfence_block();
             __syncthreads();
@@ -741,10 +785,16 @@ __device__ __forceinline__ void lf_free_body(const KConst& kc, const SrcArrays& 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int t = fresh_tid(), v = t >> 6;
                 const int nB = fa.nchB > 0 ? fa.nslot : 0, nC = fa.nchC > 0 ? fa.nslot : 0;
-                if (v < nw)
+                if (v < nw) {
                     finalize_wave<true>(fa.partA, fa.nchA, fa.nchA, fa.partB, nB, nB, nC > 0 ? fa.partC : nullptr, nC, (int)STAT_CELLS,
                                         sstat - w0, sbase - w0, w0 + v, t & 63, ap, fa.out, nullptr, nullptr, 0,
                                         STEP ? sprop + v * 16 : nullptr, STEP ? szz + v : nullptr, STEP ? spre + 2 * v : nullptr);
+                    if (fa.poll) {                // (the slots empty again: the next launch's tiles may poll)
+                        const int ln = t & 63;
+                        if (ln < nC) __hip_atomic_store(fa.partC + (size_t)(w0 + v) * fa.nslot + ln, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ln < nB) __hip_atomic_store(fa.partB + (size_t)(w0 + v) * fa.nslot + ln, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (t < QSTRIDE) q[t] = 0;        // the tile's counters, for the next launch
             }
         }

@@ -1655,7 +1655,7 @@ __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int
                                               const double* partR, int nchR, int alt_flag, const int* wstat, const double* wbase,
                                               int w, int lane, const AcceptArgs& ap, double* out, double* outA, double* outB,
                                               int a_flag = 0, const double* l_prop = nullptr, const double* l_zz = nullptr,
-                                              const double* l_pre = nullptr) {
+                                              const double* l_pre = nullptr, const double* polled = nullptr) {
     auto ld = [](const double* p) -> double {
         if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return *p;
@@ -1681,6 +1681,12 @@ __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int
     if (resc) nchA = nchR;
     // (a_flag: per-source partials were only made for walkers with this flag - fixed completeness, careful path)
     else if (a_flag && !(st & a_flag)) nchA = 0;
+    if (polled) {
+        // (lf_free's polling finisher: the lane's slot of partR and of partB is in hand - at most 64 slots apiece, so the sums
+        // below are the ones the loops would make; a walker that is not on the cells has no sources either, and is -inf)
+        a = resc && lane < nchR ? polled[0] : 0.0;
+        b = lane < nchB ? polled[1] : 0.0;
+    } else {
     // four independent running sums per lane so that the loads are in flight together (latency kernel)
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int c = lane;
@@ -1693,6 +1699,7 @@ __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int
     for (; c < nchA; c += 64) a += ld(pa + c);
     a = (a + a1) + (a2 + a3);
     for (c = lane; c < nchB; c += 64) b += ld(pb + c);
+    }
     a = wave_sum_dpp(a);                            // totals in lane 63
     b = wave_sum_dpp(b);
     if (lane == 63) {

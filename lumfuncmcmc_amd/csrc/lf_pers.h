@@ -46,6 +46,8 @@ struct PersArgs {
     const double* wrec;       // !FUSED: lf_prepare's records
     const int* wmode;
     const int* wstat;
+    int poll;                 // 1: the slots of partB / partC are PART_EMPTY: tiles without a careful path hand over by polling (lf_free.h)
+    int* err;
 };
 
 // STEP (with FUSED): the launch is a half-step of the device-resident sampler (lf_free.h: lf_free_body)
@@ -53,7 +55,7 @@ template <int VARIANT, bool FUSED, bool STEP>
 __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& pa, const StepArgs& sp, const AcceptArgs& ap) {
     static_assert(VARIANT == LF_ZEVOL || VARIANT == LF_FIXCOMP, "the free variant has lf_free");
     auto pstore = [](double* p, double v) {                 // (see lf_free: partial sums are written THROUGH in the one-launch form)
-        if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FUSED) __hip_atomic_store(p, v == v ? v : __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (never PART_EMPTY)
         else *p = v;
     };
     __shared__ MathTables tab;
@@ -369,7 +371,34 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
                 }
             }
         }
-        if (FUSED) {
+        if (FUSED && pa.poll && needmask == 0) {
+            // hand-over by polling (lf_free.h: PART_EMPTY): no careful path in this tile, so every slot has its writer; this
+            // workgroup's sums are on their way, and only the tile's finisher - the last physical rank - has more to do
+            if (frank == fgroup - 1 && v < nw) {
+                const int nB = pa.nchB > 0 ? pa.nslot : 0, nC = VARIANT == LF_ZEVOL && pa.nchC > 0 ? pa.nslot : 0;
+                double* __restrict__ pb = pa.partB + (size_t)(w0 + v) * pa.nslot;
+                double* __restrict__ pc = pa.partC + (size_t)(w0 + v) * pa.nslot;
+                double pre[2] = {0.0, 0.0};
+                int tries = 0;
+                bool have;
+                do {
+                    if (lane < nC) pre[0] = __hip_atomic_load(pc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane < nB) pre[1] = __hip_atomic_load(pb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    have = !((lane < nC && (unsigned long long)__double_as_longlong(pre[0]) == PART_EMPTY) ||
+                             (lane < nB && (unsigned long long)__double_as_longlong(pre[1]) == PART_EMPTY));
+                } while (!__all(have) && ++tries < PART_POLLS);
+                if (tries >= PART_POLLS) {
+                    pre[0] = pre[1] = __builtin_nan("");
+                    if (lane == 0) atomicExch(pa.err, 1);
+                }
+                if (lane < nC) __hip_atomic_store(pc + lane, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < nB) __hip_atomic_store(pb + lane, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                finalize_wave<true>(pa.partA, 0, pa.nslot, pa.partB, nB, pa.nslot, nC > 0 ? pa.partC : nullptr, nC, (int)STAT_CELLS,
+                                    sstat - w0, sbase - w0, w0 + v, lane, ap, pa.out, nullptr, nullptr,
+                                    VARIANT == LF_FIXCOMP ? (int)STAT_SLOW : 0,
+                                    STEP ? sprop + v * 16 : nullptr, STEP ? szz + v : nullptr, STEP ? spre + 2 * v : nullptr, pre);
+            }
+        } else if (FUSED) {
             // as in lf_free: this workgroup's partial sums have been acknowledged, then it counts itself; the last of the
             // tile's workgroups to count adds the partials up (finalize_wave: lf_finalize's body, the same slots and order)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -380,11 +409,16 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
             if (sdone == fgroup - 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int nC = VARIANT == LF_ZEVOL && pa.nchC > 0 ? pa.nslot : 0;
-                if (v < nw)
+                if (v < nw) {
                     finalize_wave<true>(pa.partA, pa.nslot, pa.nslot, pa.partB, pa.nslot, pa.nslot, nC > 0 ? pa.partC : nullptr, nC, (int)STAT_CELLS,
                                         sstat - w0, sbase - w0, w0 + v, lane, ap, pa.out, nullptr, nullptr,
                                         VARIANT == LF_FIXCOMP ? (int)STAT_SLOW : 0,       // (FIXCOMP: per-source partials exist for SLOW walkers only)
                                         STEP ? sprop + v * 16 : nullptr, STEP ? szz + v : nullptr, STEP ? spre + 2 * v : nullptr);
+                    if (pa.poll) {                // (the slots empty again: the next launch's tiles may poll)
+                        if (lane < nC) __hip_atomic_store(pa.partC + (size_t)(w0 + v) * pa.nslot + lane, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane < pa.nslot) __hip_atomic_store(pa.partB + (size_t)(w0 + v) * pa.nslot + lane, __longlong_as_double((long long)PART_EMPTY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (tid < QSTRIDE) q[tid] = 0;    // the tile's counters, for the next launch
             }
         }

@@ -83,6 +83,9 @@ struct lf_ctx {
     int64_t opt_fuse = 1;               // lf_free: prepare and finalize inside the one launch (plain evaluations)
     int64_t opt_fuse_step = 1;          // ... and the sampler's half-step too (0: three launches per half-step, A/B runs)
     bool queue_zero = false;            // d_queue is all zeros (what a fused launch needs and leaves behind)
+    bool parts_empty = false;           // every slot of d_partB / d_partR is lf::PART_EMPTY (what lf_free's polling hand-over needs and leaves behind)
+    int* d_err = nullptr;               // device error word (a finisher gave up polling)
+    int64_t opt_poll = 1;               // 0: the one-launch form hands over through the tile's counter only (A/B runs)
     int64_t opt_free_st = 0;            // lf_free: sources per lane, 0 = chosen from N and B, else 2 / 4 / 8 (tuning runs)
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
@@ -462,6 +465,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         release(c->d_partR);
         LF_HIP(c, hipMalloc((void**)&c->d_partR, partR * sizeof(double)));
         c->cap_partR = partR;
+        c->parts_empty = false;
     }
     if (partB > c->cap_partB) {
         LF_HIP(c, hipDeviceSynchronize());
@@ -469,6 +473,7 @@ int ensure_workspace(lf_ctx* c, int Bpad, size_t partA, size_t partB, size_t par
         release(c->d_partB);
         LF_HIP(c, hipMalloc((void**)&c->d_partB, partB * sizeof(double)));
         c->cap_partB = partB;
+        c->parts_empty = false;
     }
     return LF_OK;
 }
@@ -703,6 +708,20 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
         LF_HIP(c, hipMemsetAsync(c->d_queue, 0, (size_t)c->cap_queue * sizeof(int), s));
         c->queue_zero = true;
     }
+    // the polling hand-over (lf_free.h: PART_EMPTY) wants every slot of the two partial-sum buffers empty; a fused launch
+    // leaves them so, every other form leaves sums behind
+    const bool poll = fused && c->opt_poll && nslot <= 64;
+    if (poll && !c->parts_empty) {
+        static_assert((PART_EMPTY >> 32) == (PART_EMPTY & 0xffffffffull), "filled by 32-bit words");
+        LF_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_partB, (int)(PART_EMPTY & 0xffffffffull), c->cap_partB * 2, s));
+        LF_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_partR, (int)(PART_EMPTY & 0xffffffffull), c->cap_partR * 2, s));
+        if (!c->d_err) {
+            LF_HIP(c, hipMalloc((void**)&c->d_err, sizeof(int)));
+            LF_HIP(c, hipMemsetAsync(c->d_err, 0, sizeof(int), s));
+        }
+        c->parts_empty = true;
+    }
+    if (!poll) c->parts_empty = false;
     if (!fused) {
         c->queue_zero = false;
         Prof p(c, s, 0);
@@ -714,7 +733,8 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     FreeArgs fa{B, ntiles, nchA, nchB, nslot, g8, (int)c->opt_skip_grid, c->d_queue, c->d_partA, c->d_partB,
                 c->d_cells, c->d_nodes8, c->deal_key > 0 ? c->d_deal : nullptr, c->d_cc_len, c->d_cc_field, nchC, c->d_partR, c->d_wstat,
                 d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat, c->d_wbase,
-                gq ? c->gridq.d_rec : nullptr, gq ? c->gridq.d_omega : nullptr, gq ? c->gridq.d_rows : nullptr, gq ? c->gridq.nb : 0};
+                gq ? c->gridq.d_rec : nullptr, gq ? c->gridq.d_omega : nullptr, gq ? c->gridq.d_rows : nullptr, gq ? c->gridq.nb : 0,
+                poll ? 1 : 0, c->d_err};
     {
         Prof p(c, s, 1);
         if (nchA + nchB > 0) {
@@ -774,13 +794,24 @@ int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, doubl
         LF_HIP(c, hipMemsetAsync(c->d_queue, 0, (size_t)c->cap_queue * sizeof(int), s));
         c->queue_zero = true;
     }
+    const bool poll = fused && c->opt_poll;       // (lf_free.h: PART_EMPTY; see enqueue_free)
+    if (poll && !c->parts_empty) {
+        LF_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_partB, (int)(PART_EMPTY & 0xffffffffull), c->cap_partB * 2, s));
+        LF_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_partR, (int)(PART_EMPTY & 0xffffffffull), c->cap_partR * 2, s));
+        if (!c->d_err) {
+            LF_HIP(c, hipMalloc((void**)&c->d_err, sizeof(int)));
+            LF_HIP(c, hipMemsetAsync(c->d_err, 0, sizeof(int), s));
+        }
+        c->parts_empty = true;
+    }
+    if (!poll) c->parts_empty = false;
     if (!fused) {
         Prof p(c, s, 0);
         hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
                            c->d_wstat, c->d_wmode, c->d_wbase, (int*)nullptr, c->d_queue, 0);
     }
     const PersArgs pa{B, ntiles, nchB, nchC, c->ncell, nslot, g8, c->d_queue, c->d_partA, c->d_partB, c->d_partR, c->d_nodes4, c->d_zcol,
-                      c->d_cells, c->d_lum, c->d_a1, c->d_P, c->d_U, d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat};
+                      c->d_cells, c->d_lum, c->d_a1, c->d_P, c->d_U, d_theta, d_out, c->d_wrec, c->d_wmode, c->d_wstat, poll ? 1 : 0, c->d_err};
     {
         Prof p(c, s, 1);
         const dim3 grid((unsigned)(8 * g8));
@@ -844,6 +875,7 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
         return c->kc.variant == LF_FIXCOMP ? enqueue_pers_v<LF_FIXCOMP>(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap)
                                            : enqueue_pers_v<LF_ZEVOL>(c, d_theta, B, d_out, d_outA, d_outB, s, sp, ap);
     }
+    c->parts_empty = false;           // (lf_main leaves sums in the partial-sum buffers: the polling hand-over refills them)
     // compressed catalogue: piece A over the weighted pseudo-sources, plus rescue workgroups over the real one
     const bool cmp = c->opt_compress && c->cmp.built && c->kc.variant != LF_FIXCOMP;
     int gi = pick_geometry(c, B);
@@ -1170,6 +1202,7 @@ void free_ctx(lf_ctx* c) {
     if (c->d_cells) hipFree(c->d_cells);
     if (c->d_cc_start) hipFree(c->d_cc_start);
     if (c->d_deal) hipFree(c->d_deal);
+    if (c->d_err) hipFree(c->d_err);
     if (c->d_cc_len) hipFree(c->d_cc_len);
     if (c->d_cc_field) hipFree(c->d_cc_field);
     {
@@ -1661,6 +1694,19 @@ static int host_eval(lf_ctx* c, const double* theta, int B, double* out, double*
         LF_HIP(c, hipMemcpyAsync(c->h_out + 2 * (size_t)B, c->d_outB, ob, hipMemcpyDeviceToHost, c->stream));
     }
     LF_HIP(c, hipStreamSynchronize(c->stream));
+    if (out && c->d_err) {
+        // lnprob is never NaN - unless a polling finisher gave up (lf_free.h: PART_POLLS): then say so instead of handing NaN on
+        bool nan = false;
+        for (int i = 0; i < B; ++i) nan = nan || c->h_out[i] != c->h_out[i];
+        if (nan) {
+            int e = 0;
+            LF_HIP(c, hipMemcpy(&e, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+            if (e) {
+                c->err = "lf_lnprob_batch: a tile's finishing workgroup waited in vain for the tile's partial sums (device stalled?)";
+                return LF_ERR_HIP;
+            }
+        }
+    }
     if (out) std::memcpy(out, c->h_out, ob);
     if (outA) {
         std::memcpy(outA, c->h_out + B, ob);
@@ -1856,6 +1902,10 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     }
     if (std::strcmp(key, "fuse_step") == 0) {
         c->opt_fuse_step = value != 0;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "poll") == 0) {
+        c->opt_poll = value != 0;
         return LF_OK;
     }
     if (std::strcmp(key, "profile_every") == 0) {
