@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rows", type=int, default=128)
     ap.add_argument("--variant", default="free")
     ap.add_argument("--opts", default="")
+    ap.add_argument("--sampler", action="store_true", help="the time line of a half-step of the device sampler instead of a plain evaluation")
     a = ap.parse_args()
     lib = os.path.join(ROOT, "tools", "liblfmcmc_stamps.so")
     src = os.path.join(ROOT, "lumfuncmcmc_amd", "csrc", "lfmcmc.hip")
@@ -49,9 +50,17 @@ def main():
         torch.cuda.synchronize()
     nb = ctx.last_launch()["workgroups"]
     nrow = nb + (nb + 7) // 8
+    ds = None
+    if a.sampler:
+        from lumfuncmcmc_amd.sampler import DeviceEnsembleSampler
+        ds = DeviceEnsembleSampler(ctx, 2 * a.rows, seed=1, capacity=400)
+        ds.run_mcmc(synth.walkers(a.variant, 2 * a.rows, seed=1), 100)
     assert L.lf_debug_stamps(ctx._h, None, nrow) == 0
-    for _ in range(3):
-        ctx.lnprob_torch(th)
+    if ds is not None:
+        ds.enqueue(None, 3)
+    else:
+        for _ in range(3):
+            ctx.lnprob_torch(th)
     torch.cuda.synchronize()
     out = np.zeros((nrow, 8), dtype=np.uint64)
     assert L.lf_debug_stamps(ctx._h, out.ctypes.data_as(ctypes.c_void_p), nrow) == 0
