@@ -183,10 +183,6 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * a workgroup writes its sums through and is done, and the tile's finishing workgroup reads the slots until none is
  * empty (at most 2^19 times: then it writes NaN and lf_lnprob_batch returns LF_ERR_HIP); 0 = every tile counts its
  * workgroups (store, wait for the acknowledgement, atomic counter; A/B runs).  Same sums in the same order: same bits.
- * "mixed": 1 (default) lets the z-evolving persistent kernel sum a walker that some field keeps off the cells over that
- * field's SOURCES (with the reference's per-term checks) and over the other fields' CELLS, instead of over the whole
- * catalogue; 0 = all fields over their sources for such a walker (A/B runs).  (Bits 8 + f set: field f counts as unsafe
- * whatever its bounds say - tests.)
  * "profile_every": see lf_set_profiling.
  * "grid_shortcut": 1 (default) lets lf_free take piece B of a FREE context whose integration grid is separable (every
  * redshift column has the same luminosity nodes: min_comp_frac = 0) over FLUX BINS instead of the S^2 lattice points: the

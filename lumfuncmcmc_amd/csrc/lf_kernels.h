@@ -40,9 +40,7 @@ constexpr int WM = 8;        // ints per (walker, field) in wmode: {mode, klo, k
 // -inf (NEGINF); the grid integral is still computed (lf_lnprob_pieces reports it).
 enum { MODE_FAST = 0, MODE_SLOW = 1, MODE_NEGINF = 2, MODE_SKIP = 3, MODE_SKIPSRC = 4 };
 enum { STAT_PRIOR_OK = 1, STAT_NEGINF = 2, STAT_SLOW = 4,      // SLOW: some field of the walker takes the careful path
-       STAT_CELLS = 8,     // FREE: piece A of this walker is summed over the catalogue's CELLS (lf_free.h), not its sources
-       STAT_MIXED = 16 };  // z-evolving, lf_pers (KConst::mixed): the fields flagged M_CELLOK over their cells, the others over
-                           // their sources - a walker that one field keeps off the cells does not pay for the whole catalogue
+       STAT_CELLS = 8 };   // FREE: piece A of this walker is summed over the catalogue's CELLS (lf_free.h), not its sources
 // Cells (FREE, real catalogue): a cell is a run of flux-neighbouring sources of one field no wider than 2 rho, stored as
 // {x_c, S_0 .. S_8}: its midpoint and the power sums S_j = sum_k (x_k - x_c)^j.  On a table piece the term is the
 // product of two degree-7 polynomials, g(t_c + sa d) h(u_c + d) = sum_j c_j d^j, so the cell's sum over its sources
@@ -77,7 +75,7 @@ enum { F_LF = 0, F_V = 1, F_CA = 2, F_CY = 3 };   // lF = log10(1e-17 Flim); V =
 __host__ __device__ constexpr int RF(int f, int slot) { return 8 + 8 * f + slot; }
 // integer keys of wmode[(w * MAXF + f) * WM + .], see lf_prepare: the per-(walker, chunk) choice of the term's form is
 // made with scalar integer compares only
-enum { M_MODE = 0, M_KLO = 1, M_KHI = 2, M_KNE = 3, M_KAC = 4, M_CELLOK = 5 };      // (M_CELLOK: STAT_MIXED walkers)
+enum { M_MODE = 0, M_KLO = 1, M_KHI = 2, M_KNE = 3, M_KAC = 4 };
 // slots of the census KConst::forms (lf_form_counts)
 enum { FORM_GENERAL = 0, FORM_GENERAL_NOEXP = 1, FORM_TABLE = 2, FORM_TABLE_NOEXP = 3, FORM_CAREFUL = 4, FORM_SKIPPED = 5,
        FORM_NODE_GENERAL = 6, FORM_NODE_BRIGHT = 7, FORM_CELL = 8, FORM_COUNT = 9 };
@@ -91,8 +89,6 @@ struct KConst {
     int variant, fix_sch_al, nf, S, ndim;
     int specialise;           // 1: chunk-level term specialisation (term_free_noexp); 0 for A/B runs
     int cells;                // FREE, ZEVOL: 1 = the catalogue's cells exist and lf_prepare may flag walkers STAT_CELLS
-    int mixed;                // ZEVOL, set in the copy lf_pers' launches are given: lf_prepare may flag walkers STAT_MIXED;
-                              // | 256 << f: treat field f as SLOW whatever its bounds say (tests: forces the mixed form)
     int cc_fstart[MAXF + 1];  // FREE: cell chunks (64 cells) of field f are [cc_fstart[f], cc_fstart[f + 1])
     int zgrid_cols;           // ZEVOL: 1 = the grid's nodes are stored column by column (node = k S + j) and S >= BLOCK / (ZCOLS - 1),
                               // so that a chunk of BLOCK nodes touches at most ZCOLS redshift columns (gridsum_body)
@@ -460,7 +456,7 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
             // an UPPER bound of 10^tmax is all the test needs (single-precision hardware exp2, rounded up; NaN fails the test)
             const double vb = tmax < 2.9 ? (double)(__builtin_amdgcn_exp2f((float)tmax * 3.3219285f) * 1.0001f) + 1.0e-30 : 1.0e300;
             const double lb = LF_LNLN10 + LF_LN10 * phmn + fmin(c1 * tmin, c1 * tmax) - vb;
-            m = (vb < 700.0 && lb > SAFE && lb + kf.a_min > SAFE) && !((kc.mixed >> (8 + f)) & 1) ? MODE_FAST : MODE_SLOW;
+            m = (vb < 700.0 && lb > SAFE && lb + kf.a_min > SAFE) ? MODE_FAST : MODE_SLOW;
         }
     } else {
         const double Lstar = th[0], phistar = th[1];
@@ -583,17 +579,12 @@ __device__ __forceinline__ void prepare_lane(const KConst& kc, const StepArgs& s
     // cells: only walkers whose every field is FAST and inside the tables (all the others are rare, and summed per source)
     const int nocell = group8_or(has_f && !(cell_ok && (m == MODE_FAST || kf.nsrc == 0)) ? 1 : 0);
     const int cells = kc.cells && (variant == LF_FREE ? nqueue > 0 : variant == LF_ZEVOL) && !bad && !neginf && !nocell;
-    // ... or some of its fields are (z-evolving, lf_pers): those over their cells, the others over their sources
-    const int fcell = has_f && kf.nsrc > 0 && cell_ok && m == MODE_FAST ? 1 : 0;
-    const int mixed = (kc.mixed & 1) && variant == LF_ZEVOL && kc.cells && !bad && !neginf && nocell && group8_or(fcell);
     if (live && has_f) {
-        int* km = TOLDS ? reinterpret_cast<int*>(l_fc + (grp * MAXF + f) * 8 + 4) : wmode + ((size_t)w * MAXF + f) * WM;
-        km[M_MODE] = m;
-        if (variant == LF_ZEVOL) km[M_CELLOK] = fcell;
+        if (TOLDS) reinterpret_cast<int*>(l_fc + (grp * MAXF + f) * 8 + 4)[M_MODE] = m;
+        else wmode[((size_t)w * MAXF + f) * WM + M_MODE] = m;
     }
     if (live && f == 0) {
-        const int st = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0) | (cells ? STAT_CELLS : 0) |
-                       (mixed ? STAT_MIXED : 0);
+        const int st = (bad ? 0 : STAT_PRIOR_OK) | (neginf ? STAT_NEGINF : 0) | (slow ? STAT_SLOW : 0) | (cells ? STAT_CELLS : 0);
         if (TOLDS) {
             l_base[grp] = base;
             l_stat[grp] = st;
@@ -1707,9 +1698,6 @@ __device__ __forceinline__ void finalize_wave(const double* partA, int nchA, int
     }
     for (; c < nchA; c += 64) a += ld(pa + c);
     a = (a + a1) + (a2 + a3);
-    // (STAT_MIXED - z-evolving, lf_pers: some fields over their sources, in partA, the others over their cells, in partR)
-    if (partR != nullptr && (st & STAT_MIXED))
-        for (c = lane; c < nchR; c += 64) a += ld(partR + (size_t)w * nchR + c);
     for (c = lane; c < nchB; c += 64) b += ld(pb + c);
     }
     a = wave_sum_dpp(a);                            // totals in lane 63

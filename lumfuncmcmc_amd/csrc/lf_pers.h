@@ -132,7 +132,6 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
                 const int w = tid / MAXF, f = tid - w * MAXF;
                 wfc[tid * 8] = pa.wrec[(size_t)(w0 + w) * REC + RF(f, 0)];
                 reinterpret_cast<int*>(wfc + tid * 8 + 4)[M_MODE] = pa.wmode[((size_t)(w0 + w) * MAXF + f) * WM + M_MODE];
-                reinterpret_cast<int*>(wfc + tid * 8 + 4)[M_CELLOK] = pa.wmode[((size_t)(w0 + w) * MAXF + f) * WM + M_CELLOK];
             }
             if (tid >= 64 && tid < 128) {         // walker scalars
                 const int t = tid - 64, w = t >> 3, j = t & 7;
@@ -153,22 +152,19 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
             const bool in = tid < nw;
             const bool live = in && (st & STAT_PRIOR_OK) && !(st & STAT_NEGINF);
             const bool on = VARIANT == LF_ZEVOL && pa.nchC > 0 && in && (st & STAT_CELLS);
-            const bool mix = VARIANT == LF_ZEVOL && pa.nchC > 0 && live && (st & STAT_MIXED);       // (cells AND sources, by field)
             const bool need = live && (VARIANT == LF_FIXCOMP ? (st & STAT_SLOW) != 0 : !on);
-            const int mc = (int)__ballot(on || mix), mn = (int)__ballot(need), mo = (int)__ballot(in && !(st & STAT_PRIOR_OK));
-            const int mm = (int)__ballot(mix);
+            const int mc = (int)__ballot(on), mn = (int)__ballot(need), mo = (int)__ballot(in && !(st & STAT_PRIOR_OK));
             if (tid == 0) {
                 smask[0] = mc;
                 smask[1] = mn;
                 smask[2] = mo;
-                smask[3] = mm;
             }
         }
         __syncthreads();
 #ifdef LF_STAMPS
         t_prep = __builtin_amdgcn_s_memtime();
 #endif
-        const int cellmask = uni(smask[0]), needmask = uni(smask[1]), outmask = uni(smask[2]), mixmask = uni(smask[3]);
+        const int cellmask = uni(smask[0]), needmask = uni(smask[1]), outmask = uni(smask[2]);
         const bool mine_w = v < nw;               // this wave's walker exists
         const bool grid_w = mine_w && !((outmask >> v) & 1);      // (outside the prior: the grid is not evaluated, lumfuncmcmc.py:408)
         const double* __restrict__ sc = wsc + v * 8;
@@ -205,16 +201,6 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
 #pragma unroll
                     for (int k = 0; k < 8; ++k) cd[k] = nx[k];
                     if (cc + VF < pa.nchC) load_cell(nx, cc + VF);
-                    if ((mixmask >> v) & 1) {             // (STAT_MIXED: only the cells of the fields flagged M_CELLOK count)
-                        const int ci = cc * 64 + lane;
-                        int fld = 0;
-#pragma unroll
-                        for (int k = 1; k < MAXF; ++k) fld += ci >= kc.cc_fstart[k] ? 1 : 0;
-                        if (!reinterpret_cast<const int*>(wfc + (v * MAXF + fld) * 8 + 4)[M_CELLOK]) {
-#pragma unroll
-                            for (int k = 1; k < 8; ++k) cd[k] = 0.0;
-                        }
-                    }
                     asm volatile("; LF_BEGIN pzcell items=1");
                     const double zc2 = cd[0] * cd[0];
                     const double Lc = quad_nofma(aL, bL, cL, cd[0], zc2);
@@ -340,9 +326,7 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
                 for (int f = 0; f < kc.nf; ++f) {
                     const int n = kc.nsrc[f];
                     const int mode = uni(reinterpret_cast<const int*>(wfc + (w * MAXF + f) * 8 + 4)[M_MODE]);
-                    const bool oncells = VARIANT == LF_ZEVOL && ((mixmask >> w) & 1) &&
-                                         uni(reinterpret_cast<const int*>(wfc + (w * MAXF + f) * 8 + 4)[M_CELLOK]) != 0;
-                    if ((VARIANT == LF_FIXCOMP ? mode == MODE_SLOW : mode <= MODE_SLOW) && !oncells) {
+                    if (VARIANT == LF_FIXCOMP ? mode == MODE_SLOW : mode <= MODE_SLOW) {
 #pragma unroll 1
                         for (int i = vr * PB + tid; i < n; i += VF * PB) {
                             const size_t g = (size_t)(start + i);

@@ -86,7 +86,6 @@ struct lf_ctx {
     bool parts_empty = false;           // every slot of d_partB / d_partR is lf::PART_EMPTY (what lf_free's polling hand-over needs and leaves behind)
     int* d_err = nullptr;               // device error word (a finisher gave up polling)
     int64_t opt_poll = 1;               // 0: the one-launch form hands over through the tile's counter only (A/B runs)
-    int64_t opt_mixed = 1;              // z-evolving, lf_pers: 1 = STAT_MIXED walkers (KConst::mixed); | 256 << f forces field f SLOW (tests)
     int64_t opt_free_st = 0;            // lf_free: sources per lane, 0 = chosen from N and B, else 2 / 4 / 8 (tuning runs)
     int64_t opt_geometry = -1;          // index into GEOS, -1 = auto
     int64_t opt_walker_tile = 0;        // walkers per workgroup (<= the geometry's maximum), 0 = auto
@@ -226,7 +225,6 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
             kc.kf_last[f] = (int)k1;
         }
         const size_t first_cell = cd.size() / rec;
-        if (wts) kc.cc_fstart[f] = (int)first_cell;       // (z-evolving: in CELLS - lf_pers tells a cell's field by it, STAT_MIXED walkers)
         for (int64_t i = lo; i < hi;) {
             int64_t j = i + 1;
             while (j < hi && x[(size_t)j] - x[(size_t)i] <= 2.0 * rho) ++j;
@@ -265,8 +263,8 @@ int build_cells(lf_ctx* c, lf::KConst& kc, const std::vector<double>& x, int nf,
         }
     }
     const size_t ncell = cd.size() / rec;
-    {                                                                 // (a field without cells starts where the next one does)
-        for (int f = nf; f <= MAXF; ++f) kc.cc_fstart[f] = wts ? (int)ncell : (int)cst.size();
+    if (!wts) {                                                       // (a field without cells starts where the next one does)
+        for (int f = nf; f <= MAXF; ++f) kc.cc_fstart[f] = (int)cst.size();
         for (int f = nf - 1; f >= 0; --f)
             if (c->field_ind[f + 1] <= c->field_ind[f]) kc.cc_fstart[f] = kc.cc_fstart[f + 1];
     }
@@ -787,8 +785,6 @@ int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, doubl
         c->queue_zero = false;
     }
     const bool stepf = sp.enabled && ap.enabled && c->opt_fuse_step;       // the sampler's half-step: one launch too
-    KConst kcm = c->kc;                    // (this kernel serves STAT_MIXED walkers: lf_prepare / the prologue may flag them)
-    kcm.mixed = VARIANT == LF_ZEVOL && nchC > 0 ? (int)c->opt_mixed : 0;
     const bool fused = c->opt_fuse && (stepf || (!sp.enabled && !ap.enabled)) && !d_outA && !d_outB && d_out && c->profiling < 2;
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
@@ -811,7 +807,7 @@ int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, doubl
     if (!poll) c->parts_empty = false;
     if (!fused) {
         Prof p(c, s, 0);
-        hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, kcm, sp, d_theta, B, c->d_wrec,
+        hipLaunchKernelGGL(lf_prepare, dim3((B + 7) / 8), dim3(64), 0, s, c->kc, sp, d_theta, B, c->d_wrec,
                            c->d_wstat, c->d_wmode, c->d_wbase, (int*)nullptr, c->d_queue, 0);
     }
     const PersArgs pa{B, ntiles, nchB, nchC, c->ncell, nslot, g8, c->d_queue, c->d_partA, c->d_partB, c->d_partR, c->d_nodes4, c->d_zcol,
@@ -821,9 +817,9 @@ int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, doubl
         const dim3 grid((unsigned)(8 * g8));
         const int info[8] = {0, PTW, PTW, fused ? 5 : 4, (int)grid.x, nchC, nchB, B};
         std::memcpy(c->last_launch, info, sizeof(info));
-        if (fused && stepf) hipLaunchKernelGGL((lf_pers_step<VARIANT>), grid, dim3(PB), 0, s, kcm, pa, sp, ap);
-        else if (fused) hipLaunchKernelGGL((lf_pers<VARIANT, true>), grid, dim3(PB), 0, s, kcm, pa);
-        else hipLaunchKernelGGL((lf_pers<VARIANT, false>), grid, dim3(PB), 0, s, kcm, pa);
+        if (fused && stepf) hipLaunchKernelGGL((lf_pers_step<VARIANT>), grid, dim3(PB), 0, s, c->kc, pa, sp, ap);
+        else if (fused) hipLaunchKernelGGL((lf_pers<VARIANT, true>), grid, dim3(PB), 0, s, c->kc, pa);
+        else hipLaunchKernelGGL((lf_pers<VARIANT, false>), grid, dim3(PB), 0, s, c->kc, pa);
     }
     if (!fused) {
         Prof p(c, s, 3);
@@ -1910,10 +1906,6 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     }
     if (std::strcmp(key, "poll") == 0) {
         c->opt_poll = value != 0;
-        return LF_OK;
-    }
-    if (std::strcmp(key, "mixed") == 0) {
-        c->opt_mixed = value;
         return LF_OK;
     }
     if (std::strcmp(key, "profile_every") == 0) {

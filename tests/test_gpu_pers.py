@@ -111,43 +111,3 @@ def test_source_shards_split_the_grid_in_the_same_granules_in_both_kernels():
             tot += ctx.lnprob_pieces(th)[1]
         ctx.close()
         np.testing.assert_allclose(tot, bfull, rtol=1e-13)
-
-
-@pytest.mark.parametrize("zslices", [0, 8])
-def test_mixed_walkers_take_cells_for_some_fields_and_sources_for_the_others(zslices):
-    """STAT_MIXED (z-evolving, lf_pers; option "mixed"): a walker that ONE field keeps off the cells is summed over that
-    field's sources and over the other fields' cells - not over the whole catalogue.  Forced here for every walker (option
-    bit 256 << f: field f counts as SLOW whatever its bounds say) and compared with the same walkers all over the sources
-    (mixed off), all over the cells (nothing forced) and the oracle; the three-launch form has the same bits."""
-    from lumfuncmcmc_amd.capi import LFContext
-    inp = make_inputs("zevol", 200003, seed=231, zslices=zslices)
-    B = 72
-    th = _rows("zevol", B, 232)
-    ctx = LFContext(inp, max_batch=B)
-    base = ctx.lnprob_batch(th)                             # cells (rows 3, 4: the careful path)
-    got = {}
-    for f in (0, 1, 3):
-        ctx.set_option("mixed", 1 | (256 << f))
-        got[f] = ctx.lnprob_batch(th)
-        assert ctx.last_launch()["kernel"] == "lf_pers" and ctx.last_launch()["fused"]
-        a, b = ctx.lnprob_pieces(th)                        # three launches around the same kernel
-        ctx.set_option("fuse", 0)
-        np.testing.assert_array_equal(ctx.lnprob_batch(th), got[f])
-        ctx.set_option("fuse", 1)
-        ctx.set_option("mixed", 0 | (256 << f))             # the same field forced, no mixing: every field over its sources
-        plain = ctx.lnprob_batch(th)
-        assert np.array_equal(np.isinf(plain), np.isinf(got[f]))
-        fin = np.isfinite(plain)
-        np.testing.assert_allclose(got[f][fin], plain[fin], rtol=1e-13)
-        np.testing.assert_allclose((a - b)[fin], plain[fin], rtol=1e-13)
-    ctx.set_option("mixed", 1)
-    np.testing.assert_array_equal(ctx.lnprob_batch(th), base)
-    ctx.close()
-    fin = np.isfinite(base)
-    assert fin.sum() > B // 2
-    for f in got:
-        assert np.array_equal(np.isinf(got[f]), np.isinf(base))
-        np.testing.assert_allclose(got[f][fin], base[fin], rtol=1e-13)
-    with np.errstate(all="ignore"):
-        ref = O.lnprob_batch(inp, th[:8])
-    compare_rows(got[1][:8], ref, inp, th[:8], 1e-12)
