@@ -291,7 +291,7 @@ def fence_light(leg):
     torch.cuda.current_stream().synchronize()
 
 
-def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1):
+def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1, profile_span=1):
     """W warm-up + settle steps, then `steps` timed steps between two fences.  Returns (seconds, kernel times, last out)."""
     import gc
     for i in range(warmup):
@@ -327,7 +327,11 @@ def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1)
     # before it (tools/call_period.py: 39.7 us per evaluation without events, 47.3 us with a pair around every lf_main).
     # So only every `profile_every`-th evaluation of the timed steps is bracketed - still live, still in the timed
     # region, on the launch stream; "launches" in the roofline object is the number that were.
+    # ... and where an evaluation is ONE launch, a pair goes around a run of `profile_span` consecutive evaluations: the run's
+    # average is a launch's duration as the stream sees it (a pair around a single launch adds its dispatch: 16.6 us
+    # where rocprofv3 and the period of back-to-back calls say 13.6)
     leg.ctx.set_option("profile_every", max(int(profile_every), 1))
+    leg.ctx.set_option("profile_span", max(int(profile_span), 1))
     leg.ctx.set_profiling(profile_level)
     t0 = time.perf_counter()
     dbg = []
@@ -341,8 +345,10 @@ def timed(leg, fence, warmup, steps, profile_level, agree=None, profile_every=1)
     if os.environ.get("LF_BENCH_DEBUG"):
         print("debug: host time after each step (ms):", " ".join("%.2f" % (x * 1e3) for x in dbg[:8]), "fence done %.2f" % (dt * 1e3), file=sys.stderr)
     leg.ctx.set_profiling(0)
+    kt = leg.ctx.kernel_times()
     leg.ctx.set_option("profile_every", 1)
-    return dt, leg.ctx.kernel_times(), out
+    leg.ctx.set_option("profile_span", 1)
+    return dt, kt, out
 
 
 def census(leg, used):
@@ -490,7 +496,10 @@ def roofline_of(args, leg, model, kt, dt):
             "traffic": traffic, "avg_launch_ms": avg_ms, "launches": launches, "rocprofv3_avg_launch_ms": rocprof_ms,
             "traffic_and_rocprofv3_from": "profiles/hbm_traffic.json (the committed rocprofv3 passes of this command; not measured by this run)"
             if traffic is not None else None,
-            "launches_timed": "every %d-th of the timed region's %d, HIP events on the launch stream" % (max(args.profile_every, 1), 2 * args.steps),
+            "launches_timed": ("HIP events on the launch stream: one pair around each run of %d consecutive evaluations (one launch each) starting at "
+                               "every %d-th of the timed region's %d; avg_launch_ms is the runs' average per launch"
+                               % (args.profile_span, max(args.profile_every, 1), 2 * args.steps)) if args.profile_span > 1 and launch.get("fused")
+            else "every %d-th of the timed region's %d, HIP events on the launch stream" % (max(args.profile_every, 1), 2 * args.steps),
             "measured_on": "rank 0",
             "launch": launch, "terms_per_launch": terms,
             "flops_per_launch": {"source_terms": src_flops, "grid_integral": grid_flops},
@@ -586,6 +595,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
+    ap.add_argument("--profile-span", type=int, default=10,
+                    help="one-launch evaluations: one event pair around this many consecutive evaluations (their average); 1 = a pair per launch")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="bracket only every n-th evaluation of the timed steps with events (each pair is two barrier packets and stalls "
                          "the stream 8-12 us - most of an evaluation by now); 0 = as many as give two bracketed launches in the timed steps")
@@ -657,7 +668,9 @@ def main():
     ctx, ndim, half = leg.ctx, leg.ndim, leg.half
     if args.profile_every <= 0:
         args.profile_every = max(args.steps, 1)                 # (two evaluations per step: two bracketed launches in the timed steps)
-    dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level, agree=reduce_max, profile_every=args.profile_every)
+    args.profile_span = max(1, min(args.profile_span, args.profile_every))
+    dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level, agree=reduce_max, profile_every=args.profile_every,
+                        profile_span=args.profile_span)
     dt = reduce_max(dt)
     assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all(), "non-finite lnprob in the timed workload"
     step, theta_all, nblk = leg.step, leg.theta_all, leg.nblk

@@ -183,7 +183,9 @@ int lf_kernel_times(lf_ctx *ctx, double ms[4], int64_t launches[4]);
  * a workgroup writes its sums through and is done, and the tile's finishing workgroup reads the slots until none is
  * empty (at most 2^19 times: then it writes NaN and lf_lnprob_batch returns LF_ERR_HIP); 0 = every tile counts its
  * workgroups (store, wait for the acknowledgement, atomic counter; A/B runs).  Same sums in the same order: same bits.
- * "profile_every": see lf_set_profiling.
+ * "profile_every": see lf_set_profiling.  "profile_span": n > 1 puts ONE event pair around n consecutive one-launch
+ * evaluations (profiling level 1) instead of a pair around a single launch, and lf_kernel_times counts n launches for it:
+ * a pair of barrier packets around one 13-us launch adds its dispatch to the figure (16.6 us where the profiler says 13.7).
  * "grid_shortcut": 1 (default) lets lf_free take piece B of a FREE context whose integration grid is separable (every
  * redshift column has the same luminosity nodes: min_comp_frac = 0) over FLUX BINS instead of the S^2 lattice points: the
  * completeness depends on a lattice point only through its log flux L_j - D_k, so per bin the lattice points of a row are

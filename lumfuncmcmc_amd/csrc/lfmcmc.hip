@@ -37,6 +37,7 @@ struct ChunkTable {
 struct EventPair {
     hipEvent_t a, b;
     int kind;
+    int count = 1;        // launches between the two events (option "profile_span")
 };
 
 // compressed catalogue (lf_compress.h): weighted pseudo-sources, sources of a field contiguous
@@ -138,6 +139,12 @@ struct lf_ctx {
     lf::ZCells zcells{};                // ZEVOL, real catalogue: the cell workgroups' arguments for the launch being enqueued (nchC = 0: none)
     int64_t opt_profile_every = 1;      // ... of every n-th evaluation only (an event pair costs the stream ~4 us: it drains the queue)
     int64_t prof_tick = 0;
+    int64_t opt_profile_span = 1;       // one event pair around this many CONSECUTIVE one-launch evaluations (their average: a pair of
+                                        // barrier packets around every single launch adds the dispatch to it)
+    int64_t prof_pos = 0;               // this evaluation's place in its period of opt_profile_every
+    bool prof_span_ok = false;          // this evaluation is one launch (spans make sense)
+    bool span_open = false;
+    EventPair span_ep{};
     bool prof_this = true;              // (this evaluation is one of them)
     std::vector<EventPair> events;
     double acc_ms[4] = {0, 0, 0, 0};
@@ -483,19 +490,38 @@ struct Prof {
     hipStream_t s;
     int kind;
     EventPair ep{};
-    bool on;
-    Prof(lf_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->prof_this && (c_->profiling >= 2 || (c_->profiling == 1 && k == 1))) {
+    bool on, span;
+    Prof(lf_ctx* c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k) {
+        // (option "profile_span" = n > 1, profiling level 1, one-launch evaluations: ONE pair around n consecutive launches)
+        span = k == 1 && c->profiling == 1 && c->opt_profile_span > 1 && c->prof_span_ok;
+        on = !span && c->prof_this && (c->profiling >= 2 || (c->profiling == 1 && k == 1));
         if (on) {
             hipEventCreate(&ep.a);
             hipEventCreate(&ep.b);
             ep.kind = kind;
             hipEventRecord(ep.a, s);
         }
+        if (span && c->prof_pos == 0 && !c->span_open) {
+            hipEventCreate(&c->span_ep.a);
+            hipEventCreate(&c->span_ep.b);
+            c->span_ep.kind = kind;
+            c->span_ep.count = 0;
+            hipEventRecord(c->span_ep.a, s);
+            c->span_open = true;
+        }
     }
     ~Prof() {
         if (on) {
             hipEventRecord(ep.b, s);
             c->events.push_back(ep);
+        }
+        if (span && c->span_open) {
+            ++c->span_ep.count;
+            if (c->span_ep.count >= std::min(c->opt_profile_span, c->opt_profile_every)) {
+                hipEventRecord(c->span_ep.b, s);
+                c->events.push_back(c->span_ep);
+                c->span_open = false;
+            }
         }
     }
 };
@@ -702,7 +728,9 @@ int enqueue_free(lf_ctx* c, const double* d_theta, int B, double* d_out, double*
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->any_enqueued = true;
-    c->prof_this = c->profiling > 0 && (c->prof_tick++ % c->opt_profile_every) == 0;
+    c->prof_pos = c->prof_tick++ % c->opt_profile_every;
+    c->prof_this = c->profiling > 0 && c->prof_pos == 0;
+    c->prof_span_ok = fused;
     if (fused && !c->queue_zero) {
         // the tiles' counters start at zero; a fused launch leaves them so, lf_prepare zeroes them for the three-launch form
         LF_HIP(c, hipMemsetAsync(c->d_queue, 0, (size_t)c->cap_queue * sizeof(int), s));
@@ -789,7 +817,9 @@ int enqueue_pers_v(lf_ctx* c, const double* d_theta, int B, double* d_out, doubl
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->any_enqueued = true;
-    c->prof_this = c->profiling > 0 && (c->prof_tick++ % c->opt_profile_every) == 0;
+    c->prof_pos = c->prof_tick++ % c->opt_profile_every;
+    c->prof_this = c->profiling > 0 && c->prof_pos == 0;
+    c->prof_span_ok = fused;
     if (fused && !c->queue_zero) {
         LF_HIP(c, hipMemsetAsync(c->d_queue, 0, (size_t)c->cap_queue * sizeof(int), s));
         c->queue_zero = true;
@@ -909,7 +939,9 @@ int enqueue(lf_ctx* c, const double* d_theta, int B, double* d_out, double* d_ou
     if (c->any_enqueued && c->last_stream != s) LF_HIP(c, hipStreamSynchronize(c->last_stream));
     c->last_stream = s;
     c->any_enqueued = true;
-    c->prof_this = c->profiling > 0 && (c->prof_tick++ % c->opt_profile_every) == 0;
+    c->prof_pos = c->prof_tick++ % c->opt_profile_every;
+    c->prof_this = c->profiling > 0 && c->prof_pos == 0;
+    c->prof_span_ok = false;
 
     {
         Prof p(c, s, 0);
@@ -1740,12 +1772,22 @@ int lf_set_profiling(lf_ctx* c, int enabled) {
 int lf_kernel_times(lf_ctx* c, double ms[4], int64_t launches[4]) {
     if (!c || !ms || !launches) return LF_ERR_ARG;
     LF_HIP(c, hipSetDevice(c->device));
+    if (c->span_open) {                  // (a span cut short: what it holds so far)
+        if (c->span_ep.count > 0) {
+            hipEventRecord(c->span_ep.b, c->last_stream);
+            c->events.push_back(c->span_ep);
+        } else {
+            hipEventDestroy(c->span_ep.a);
+            hipEventDestroy(c->span_ep.b);
+        }
+        c->span_open = false;
+    }
     for (auto& e : c->events) {
         LF_HIP(c, hipEventSynchronize(e.b));
         float t = 0.f;
         LF_HIP(c, hipEventElapsedTime(&t, e.a, e.b));
         c->acc_ms[e.kind] += t;
-        c->acc_n[e.kind] += 1;
+        c->acc_n[e.kind] += e.count;
         hipEventDestroy(e.a);
         hipEventDestroy(e.b);
     }
@@ -1910,6 +1952,11 @@ int lf_set_option(lf_ctx* c, const char* key, int64_t value) {
     }
     if (std::strcmp(key, "profile_every") == 0) {
         c->opt_profile_every = value < 1 ? 1 : value;
+        c->prof_tick = 0;
+        return LF_OK;
+    }
+    if (std::strcmp(key, "profile_span") == 0) {
+        c->opt_profile_span = value < 1 ? 1 : value;
         c->prof_tick = 0;
         return LF_OK;
     }

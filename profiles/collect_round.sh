@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything the round's committed profiles come from, in one GPU session:
 #   bash profiles/collect_round.sh r03      (on the GPU box; writes gpurun_out/round_<tag>/ and gpurun_out/prof_*)
+#   BENCH_ONLY=1 bash profiles/collect_round.sh r03      (the bench lines and tools only, no rocprofv3 passes)
 set -u
 r=${1:-rNN}
 out=gpurun_out/round_$r
@@ -8,6 +9,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 # the driver's own command first (full line: cpu baseline, extras)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_default.json 2> $out/bench_default.err || echo "default bench failed"
+if [ -z "${BENCH_ONLY:-}" ]; then
 # rocprofv3 passes (kernel trace + stats; FETCH_SIZE, WRITE_SIZE, SQ counters each in a run of its own)
 PASSES="trace fetch write sq" bash profiles/collect.sh free_1000000_w256 > $out/collect_w256.log 2>&1
 BENCH_ARGS="--walkers 512" PASSES="trace fetch write" bash profiles/collect.sh free_1000000_w512 > $out/collect_w512.log 2>&1
@@ -15,6 +17,7 @@ BENCH_ARGS="--variant zevol" PASSES="trace fetch write sq" bash profiles/collect
 BENCH_ARGS="--variant fixcomp" PASSES="trace" bash profiles/collect.sh fixcomp_1000000_w256 > $out/collect_fixcomp.log 2>&1
 BENCH_ARGS="--no-cells" PASSES="trace fetch write sq" bash profiles/collect.sh free_1000000_w256_nocells > $out/collect_nocells.log 2>&1
 BENCH_ARGS="--no-grid-shortcut" PASSES="trace" bash profiles/collect.sh free_1000000_w256_nogridshortcut > $out/collect_nogq.log 2>&1
+fi
 # the same runs without the profiler (the numbers quoted next to the profiles)
 b="--steps 20 --warmup 5 --no-cpu-baseline --no-extras"
 for c in 1 2 3 5; do python3 bench.py $b --config $c > $out/bench_config$c.json 2>/dev/null; done
