@@ -108,7 +108,12 @@ __device__ __forceinline__ void lf_pers_body(const KConst& kc, const PersArgs& p
                 prepare_lane<false, true, STEP, VARIANT>(kc, sp, pa.theta, pa.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, w0 + (up >> 3), up & 7,
                                                 up >> 3, reinterpret_cast<double(*)[16]>(red), wfc, wsc, sstat, sbase, nullptr, nullptr, sprop, szz);
             } else if (!tables_loaded && tid >= 128 && tid < 128 + 256) {
-                const int t = tid - 128;
+                // (the thread number made anew: from `tid` the compiler lifts the tables' addresses out of the tile loop, up into the
+                // kernel's preamble - and in the step kernel, short of registers, spills them there and fetches them back here one
+                // by one, each load of a table behind its own trip to scratch: three dependent round trips instead of one)
+                int fm = -1;
+                asm volatile("" : "+s"(fm));
+                const int t = wave_base + __builtin_amdgcn_mbcnt_hi(fm, __builtin_amdgcn_mbcnt_lo(fm, 0)) - 128;
                 double2 lt = *reinterpret_cast<const double2*>(LOG_TABLE + 2 * t);
                 double et = EXP_TABLE[t];
                 double2 zz = VARIANT == LF_ZEVOL ? *reinterpret_cast<const double2*>(pa.zcol + 2 * min(t, kc.S - 1)) : double2{0.0, 0.0};
