@@ -85,6 +85,13 @@ typedef struct lf_desc {
 typedef struct lf_ctx lf_ctx;
 
 /* ABI version of the loaded library (== LF_ABI_VERSION of the header it was built from). */
+/* Host-only helper behind lf_free's deal of its chunks to its 32 virtual workgroups, exported so that
+ * the CPU tests can check it: table[0 .. 32] = where rank r's cell chunks start in the list, table[33 .. 65] the same for its
+ * flux bins, then the list (cell chunks rank by rank, then bins rank by rank).  table = NULL: returns the number of ints
+ * (66 + n_cell_chunks + n_bins); else fills `table` (cap ints) and returns that number.  grid_part / grid_parts as in the
+ * "grid_share" option (0, 0: the whole grid). */
+int lf_deal_table(int n_cell_chunks, int n_bins, int grid_part, int grid_parts, int32_t *table, int64_t cap);
+
 int lf_abi_version(void);
 
 /* Replaces the read side of LumFuncMCMC.__init__ / LumFuncMCMCz.__init__ (lumfuncmcmc.py:162-177):

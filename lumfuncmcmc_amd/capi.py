@@ -43,7 +43,7 @@ EXPORTS = ("lf_abi_version", "lf_create", "lf_destroy", "lf_ndim", "lf_lnprob_ba
            "lf_lnprob_batch_device", "lf_lnprob_batch_device_n", "lf_lnprob_pieces", "lf_set_profiling", "lf_kernel_times",
            "lf_set_option", "lf_last_error", "lf_sampler_create", "lf_sampler_destroy", "lf_sampler_start",
            "lf_sampler_run", "lf_sampler_read", "lf_sampler_steps", "lf_sampler_half_eval",
-           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_grid_bins", "lf_form_counts", "lf_last_launch", "lf_veff")
+           "lf_sampler_half_accept", "lf_compress_keys", "lf_compress_grid", "lf_grid_bins", "lf_deal_table", "lf_form_counts", "lf_last_launch", "lf_veff")
 
 _lib = None
 
@@ -172,6 +172,25 @@ def compress_grid(params, L, wL, ck, Dk):
     nom = int(off[nb - 1] + nrows[nb - 1] * 16)
     return {"u": u[:nb * 16].reshape(nb, 16).copy(), "row0": row0[:nb].copy(), "nrows": nrows[:nb].copy(),
             "off": off[:nb].copy(), "omega": omega[:nom].copy(), "bound": float(bound[0])}
+
+
+def deal_table(n_cell_chunks, n_bins, grid_part=0, grid_parts=0):
+    """Host-only helper behind lf_free's deal of its cell chunks and flux bins to its 32 virtual workgroups (lfmcmc.hip:
+    make_deal).  Returns (cells, bins): two lists of 32 lists - the chunk / bin numbers each rank
+    takes, in the order it takes them.  Touches no GPU."""
+    lib = load()
+    lib.lf_deal_table.restype = ctypes.c_int
+    lib.lf_deal_table.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int32), ctypes.c_int64]
+    n = lib.lf_deal_table(int(n_cell_chunks), int(n_bins), int(grid_part), int(grid_parts), None, 0)
+    if n < 0:
+        raise ValueError("lf_deal_table: bad arguments")
+    t = np.empty(n, dtype=np.int32)
+    assert lib.lf_deal_table(int(n_cell_chunks), int(n_bins), int(grid_part), int(grid_parts), t.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n) == n
+    VF = (n - n_cell_chunks - n_bins) // 2 - 1
+    lst = t[2 * (VF + 1):]
+    cells = [lst[t[v]:t[v + 1]].tolist() for v in range(VF)]
+    bins = [lst[n_cell_chunks + t[VF + 1 + v]:n_cell_chunks + t[VF + 2 + v]].tolist() for v in range(VF)]
+    return cells, bins
 
 
 def grid_bins(params, L, wL, ck, Dk):

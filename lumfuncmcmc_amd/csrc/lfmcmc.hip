@@ -635,39 +635,46 @@ int free_groups(lf_ctx* c, int slot, int ntiles, int nchA, int nchB, int nchC) {
 // 14.0 at 16; the arithmetic deal 15.25; at 256 rows, where a workgroup serves an elder and a younger rank, all within 2 %).  Bins that a source-sharded rank does not integrate (grid_share) cost nothing.  The table depends
 // on the context (numbers of cell chunks and bins, grid share) only - never on the batch.  No table (the arithmetic deal):
 // no bins, or more entries than the kernel keeps in LDS.
+// (host only; also behind lf_deal_table for the CPU tests)
+static std::vector<int> make_deal(int nchC, int nbq, int grid_part, int grid_parts) {
+    using namespace lf;
+    std::vector<int> load(VF), cnt_c(VF, 0), cnt_b(VF, 0), own_c(nchC), own_b(nbq);
+    const int cost_h = std::getenv("LF_DEAL_H") ? std::atoi(std::getenv("LF_DEAL_H")) : 8;       // (tuning runs: tools/deal_sweep.sh)
+    const int cost_b = std::getenv("LF_DEAL_B") ? std::atoi(std::getenv("LF_DEAL_B")) : 8;
+    for (int v = 0; v < VF; ++v) load[v] = v >= VF / 2 ? cost_h : 0;
+    auto next = [&]() { return (int)(std::min_element(load.begin(), load.end()) - load.begin()); };      // (ties: the lowest rank)
+    for (int b = 0; b < nbq; ++b) {
+        const int v = next();
+        own_b[b] = v;
+        ++cnt_b[v];
+        load[v] += grid_parts > 1 && b % grid_parts != grid_part ? 0 : cost_b;
+    }
+    for (int i = 0; i < nchC; ++i) {
+        const int v = next();
+        own_c[i] = v;
+        ++cnt_c[v];
+        load[v] += 3;
+    }
+    std::vector<int> t(DEAL_LIST + nchC + nbq);
+    t[0] = 0;
+    t[DEAL_BINS] = 0;
+    for (int v = 0; v < VF; ++v) {
+        t[v + 1] = t[v] + cnt_c[v];
+        t[DEAL_BINS + v + 1] = t[DEAL_BINS + v] + cnt_b[v];
+    }
+    std::vector<int> at_c(t.begin(), t.begin() + VF), at_b(t.begin() + DEAL_BINS, t.begin() + DEAL_BINS + VF);
+    for (int i = 0; i < nchC; ++i) t[DEAL_LIST + at_c[own_c[i]]++] = i;
+    for (int b = 0; b < nbq; ++b) t[DEAL_LIST + nchC + at_b[own_b[b]]++] = b;
+    return t;
+}
+
 int ensure_deal(lf_ctx* c, int nchC, int nbq, hipStream_t s) {
     using namespace lf;
     const int64_t key = nbq <= 0 || DEAL_LIST + nchC + nbq > DEAL_MAX || std::getenv("LF_NO_DEAL")      // (the variable: A/B runs)
                             ? 0 : 1 + nchC + 4096ll * nbq + (4096ll * 4096) * (c->kc.grid_part + 4096ll * c->kc.grid_parts);
     if (key == c->deal_key) return LF_OK;
     if (key > 0) {
-        std::vector<int> load(VF), cnt_c(VF, 0), cnt_b(VF, 0), own_c(nchC), own_b(nbq);
-        const int cost_h = std::getenv("LF_DEAL_H") ? std::atoi(std::getenv("LF_DEAL_H")) : 8;       // (tuning runs: tools/deal_sweep.sh)
-        const int cost_b = std::getenv("LF_DEAL_B") ? std::atoi(std::getenv("LF_DEAL_B")) : 8;
-        for (int v = 0; v < VF; ++v) load[v] = v >= VF / 2 ? cost_h : 0;
-        auto next = [&]() { return (int)(std::min_element(load.begin(), load.end()) - load.begin()); };      // (ties: the lowest rank)
-        for (int b = 0; b < nbq; ++b) {
-            const int v = next();
-            own_b[b] = v;
-            ++cnt_b[v];
-            load[v] += c->kc.grid_parts > 1 && b % c->kc.grid_parts != c->kc.grid_part ? 0 : cost_b;
-        }
-        for (int i = 0; i < nchC; ++i) {
-            const int v = next();
-            own_c[i] = v;
-            ++cnt_c[v];
-            load[v] += 3;
-        }
-        std::vector<int> t(DEAL_LIST + nchC + nbq);
-        t[0] = 0;
-        t[DEAL_BINS] = 0;
-        for (int v = 0; v < VF; ++v) {
-            t[v + 1] = t[v] + cnt_c[v];
-            t[DEAL_BINS + v + 1] = t[DEAL_BINS + v] + cnt_b[v];
-        }
-        std::vector<int> at_c(t.begin(), t.begin() + VF), at_b(t.begin() + DEAL_BINS, t.begin() + DEAL_BINS + VF);
-        for (int i = 0; i < nchC; ++i) t[DEAL_LIST + at_c[own_c[i]]++] = i;
-        for (int b = 0; b < nbq; ++b) t[DEAL_LIST + nchC + at_b[own_b[b]]++] = b;
+        const std::vector<int> t = make_deal(nchC, nbq, c->kc.grid_part, c->kc.grid_parts);
         if (!c->d_deal) LF_HIP(c, hipMalloc((void**)&c->d_deal, (size_t)DEAL_MAX * sizeof(int)));
         if (c->any_enqueued) LF_HIP(c, hipStreamSynchronize(c->last_stream));        // (a launch may still be reading the old table)
         LF_HIP(c, hipMemcpy(c->d_deal, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1611,6 +1618,17 @@ int build(lf_ctx* c, const lf_desc* d) {
 }  // namespace
 
 extern "C" {
+
+int lf_deal_table(int n_cell_chunks, int n_bins, int grid_part, int grid_parts, int32_t* table, int64_t cap) {
+    using namespace lf;
+    if (n_cell_chunks < 0 || n_bins < 0 || grid_parts < 0 || grid_part < 0 || (grid_parts > 0 && grid_part >= grid_parts)) return LF_ERR_ARG;
+    const int64_t n = (int64_t)DEAL_LIST + n_cell_chunks + n_bins;
+    if (!table) return (int)n;
+    if (cap < n) return LF_ERR_ARG;
+    const std::vector<int> t = make_deal(n_cell_chunks, n_bins, grid_part, grid_parts);
+    for (int64_t i = 0; i < n; ++i) table[i] = t[(size_t)i];
+    return (int)n;
+}
 
 int lf_abi_version(void) { return LF_ABI_VERSION; }
 
