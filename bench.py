@@ -595,7 +595,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the plumbing)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     ap.add_argument("--profile-level", type=int, default=1, help="HIP events: 0 none, 1 around lf_main, 2 every launch")
-    ap.add_argument("--profile-span", type=int, default=10,
+    ap.add_argument("--profile-span", type=int, default=20,
                     help="one-launch evaluations: one event pair around this many consecutive evaluations (their average); 1 = a pair per launch")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="bracket only every n-th evaluation of the timed steps with events (each pair is two barrier packets and stalls "
@@ -667,7 +667,9 @@ def main():
     leg = Leg(args, model, dev, local, world, rank, Wtot, shard)
     ctx, ndim, half = leg.ctx, leg.ndim, leg.half
     if args.profile_every <= 0:
-        args.profile_every = max(args.steps, 1)                 # (two evaluations per step: two bracketed launches in the timed steps)
+        # (two evaluations per step.  One-launch evaluations: ONE run of --profile-span launches under one event pair in the timed
+        # steps; forms of three launches: a pair around every steps-th evaluation's main kernel, two in all)
+        args.profile_every = max(2 * args.steps if args.profile_span > 1 else args.steps, 1)
     args.profile_span = max(1, min(args.profile_span, args.profile_every))
     dt, kt, out = timed(leg, fence, args.warmup, args.steps, args.profile_level, agree=reduce_max, profile_every=args.profile_every,
                         profile_span=args.profile_span)
